@@ -1,0 +1,319 @@
+"""Generates the committed golden vectors under tests/golden/ by RUNNING THE REFERENCE ITSELF.
+
+Runs only in the build container (needs /root/reference and oracle/_ref/*.so from `make -C oracle ref`).
+Nothing here travels to the GPU box except the .npz outputs; the reference's sources are imported in place and
+never copied.
+
+How the reference is run:
+  * `boardlaw.mcts`, `boardlaw.hex`, `boardlaw.networks` are imported from /root/reference unmodified.
+  * Its two native modules are taken from oracle/_ref (the reference's own CPU sources compiled at -O2 by
+    oracle/Makefile) by pre-seeding the loader caches `boardlaw.mcts.cuda._cache` / `boardlaw.hex.cuda._cache`
+    (boardlaw/mcts/cuda.py:5-11), so the reference's JIT loader (which needs ninja + minutes) is not involved.
+  * `aljpy` (a logging helper the reference imports in rebar/profiling.py:9, absent from this image) is replaced
+    by an in-memory module exposing `logger()`; it takes no part in any arithmetic.
+
+Usage:  python tests/golden/make_golden.py            (writes tests/golden/*.npz)
+"""
+import importlib.util
+import logging
+import os
+import sys
+import types
+import contextlib
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = os.environ.get('BOARDLAW_REFERENCE', '/root/reference')
+VARIANT = os.environ.get('GOLDEN_REF_VARIANT', '')  # '' (=-O2) or '_O0'
+
+
+def _load_ext(name, path):
+    spec = importlib.util.spec_from_file_location(name, path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def import_reference():
+    aljpy = types.ModuleType('aljpy')
+    aljpy.logger = lambda *a, **k: logging.getLogger('aljpy')
+
+    @contextlib.contextmanager
+    def timer():
+        yield None
+    aljpy.timer = timer
+    sys.modules['aljpy'] = aljpy
+    pavlov = types.ModuleType('pavlov')
+    pavlov.stats = types.ModuleType('pavlov.stats')
+    pavlov.stats.mean = lambda *a, **k: None
+    sys.modules['pavlov'] = pavlov
+    sys.modules['pavlov.stats'] = pavlov.stats
+    sys.path.insert(0, REF)
+    os.chdir('/tmp')
+    import matplotlib
+    matplotlib.use('Agg')
+    import boardlaw.mcts.cuda as mcuda
+    import boardlaw.hex.cuda as hcuda
+    mcuda._cache = _load_ext('mctscuda' + VARIANT, os.path.join(ROOT, 'oracle/_ref/mctscuda%s.so' % VARIANT))
+    hcuda._cache = _load_ext('hexcuda', os.path.join(ROOT, 'oracle/_ref/hexcuda.so'))
+    import boardlaw.mcts as mcts
+    import boardlaw.hex as hex_
+    import boardlaw.networks as networks
+    import boardlaw.validation as validation
+    return mcts, hex_, networks, validation, mcuda, hcuda
+
+
+def np_(x):
+    """tensor -> numpy, halves kept as raw uint16 bit patterns (npz-portable, bit-exact)."""
+    x = x.detach().cpu().contiguous()
+    if x.dtype == torch.half:
+        return x.view(torch.int16).numpy().view(np.uint16).copy()
+    if x.dtype == torch.bool:
+        return x.numpy().astype(np.uint8)
+    return x.numpy().copy()
+
+
+# --------------------------------------------------------------------------------------------------------------
+# 1. Hex board dynamics: random playouts through the reference's Hex world  (SURVEY 8c fixture 2)
+# --------------------------------------------------------------------------------------------------------------
+def gen_hex(hex_, hcuda, out):
+    data = {}
+    for S in (3, 4, 5, 7, 9, 11, 13):
+        torch.manual_seed(100 + S)
+        B = 24
+        worlds = hex_.Hex.initial(B, S, device='cpu')
+        rec = {k: [] for k in ('board', 'seats', 'actions', 'obs', 'valid', 'raw_board', 'rewards',
+                               'new_board', 'new_seats', 'terminal')}
+        for _ in range(3 * S * S):
+            actions = torch.distributions.Categorical(probs=worlds.valid.float()).sample()
+            raw = worlds.board.clone()
+            raw_rewards = hcuda.step(raw, worlds.seats.int(), actions.int())
+            new_worlds, trans = worlds.step(actions)
+            assert torch.equal(raw_rewards, trans.rewards)
+            rec['board'].append(np_(worlds.board)); rec['seats'].append(np_(worlds.seats))
+            rec['actions'].append(np_(actions.int())); rec['obs'].append(np_(worlds.obs).astype(np.uint8))
+            rec['valid'].append(np_(worlds.valid)); rec['raw_board'].append(np_(raw))
+            rec['rewards'].append(np_(trans.rewards)); rec['new_board'].append(np_(new_worlds.board))
+            rec['new_seats'].append(np_(new_worlds.seats)); rec['terminal'].append(np_(trans.terminal))
+            worlds = new_worlds
+        for k, v in rec.items():
+            data[f'S{S}_{k}'] = np.stack(v)
+    np.savez_compressed(os.path.join(out, 'hex_playouts.npz'), **data)
+    print('hex_playouts', sum(v.nbytes for v in data.values()) // 1024, 'KiB raw')
+
+
+# --------------------------------------------------------------------------------------------------------------
+# 2./3. Search kernels on live trees + whole searches (SURVEY 8c fixtures 1 and 3)
+# --------------------------------------------------------------------------------------------------------------
+class Recorder:
+    """Wraps the reference's native entry points (boardlaw/mcts/cuda.py:28-42) to log inputs/outputs."""
+
+    def __init__(self, mcuda, keep_ops):
+        self.mcuda, self.keep_ops = mcuda, keep_ops
+        self.ops = []       # per-op records (only for sims listed in keep_ops)
+        self.rands = []     # every descend's (B,T) f16 uniforms, in call order
+        self.sim = 0
+        self._descend, self._root, self._backup = mcuda.descend, mcuda.root, mcuda.backup
+
+    def install(self):
+        m = self.mcuda
+        m.descend, m.root, m.backup = self.descend, self.root, self.backup
+
+    def uninstall(self):
+        m = self.mcuda
+        m.descend, m.root, m.backup = self._descend, self._root, self._backup
+
+    @staticmethod
+    def tree(m):
+        return dict(logits=np_(m.logits), w=np_(m.w), n=np_(m.n), c_puct=np_(m.c_puct), seats=np_(m.seats),
+                    terminal=np_(m.terminal), children=np_(m.children))
+
+    def descend(self, m):
+        state = torch.get_rng_state()
+        rands = torch.rand_like(m.logits[:, :, 0])          # what cpu.cpp:187 is about to draw
+        torch.set_rng_state(state)
+        self.sim += 1
+        before = self.tree(m) if self.sim in self.keep_ops else None
+        d = self._descend(m)
+        self.rands.append(np_(rands))
+        if before is not None:
+            q = m.w.float() / (m.n.float().unsqueeze(-1) + 1e-4)
+            before.update(rands=np_(rands), parents=np_(d.parents), actions=np_(d.actions),
+                          root_probs=np_(self._root(m)), qminmax=np.array([q.min().item(), q.max().item()], np.float32))
+            self.ops.append(('descend', self.sim, before))
+        return d
+
+    def root(self, m):
+        return self._root(m)
+
+    def backup(self, bk, leaves):
+        # Backup exposes no properties (wrappers.cpp:67-69); the MCTS object that built it is patched to hand us
+        # the tensors via self.pending.
+        rec = None
+        if self.sim in self.keep_ops:
+            t = self.pending
+            rec = dict(v=np_(t['v']), w=np_(t['w']), n=np_(t['n']), rewards=np_(t['rewards']),
+                       parents=np_(t['parents']), terminal=np_(t['terminal']), leaves=np_(leaves))
+        self._backup(bk, leaves)
+        if rec is not None:
+            rec.update(w_after=np_(self.pending['w']), n_after=np_(self.pending['n']))
+            self.ops.append(('backup', self.sim, rec))
+
+
+class RecordingNetwork:
+    """Wraps an FCModel; logs what MCTS.initialize / MCTS.simulate (mcts/__init__.py:72-80,131-136) receive."""
+
+    def __init__(self, net):
+        self.net, self.calls = net, []
+
+    def __call__(self, world):
+        d = self.net(world)
+        self.calls.append(dict(logits=d.logits.detach().clone(), v=d.v.detach().clone(),
+                               board=world.board.clone(), seats=world.seats.clone()))
+        return d
+
+
+def run_search_fixture(mcts_mod, hex_, networks, mcuda, S, B, T, width, depth, n_moves, seed, keep_ops, mix_moves):
+    torch.manual_seed(seed)
+    worlds = hex_.Hex.initial(B, S, device='cpu')
+    for _ in range(mix_moves):
+        actions = torch.distributions.Categorical(probs=worlds.valid.float()).sample()
+        worlds, _ = worlds.step(actions)
+    net = networks.FCModel(worlds.obs_space, worlds.action_space, width=width, depth=depth)
+    # ReZero alphas start at 0 (networks.py:15) which would make the net ignore its body: perturb so value and
+    # policy depend on the position. Recorded outputs are what the replay uses, so this only adds variety.
+    with torch.no_grad():
+        for p in net.parameters():
+            if p.ndim == 0:
+                p.fill_(0.5)
+    rnet = RecordingNetwork(net)
+
+    out = dict(meta=np.array([S, B, T, width, depth, n_moves, seed], np.int64))
+    out['world0_board'] = np_(worlds.board); out['world0_seats'] = np_(worlds.seats)
+    ops_all = []
+
+    # capture Backup's tensors: patch MCTS.backup to stash them (mcts/__init__.py:97-106)
+    rec = Recorder(mcuda, keep_ops)
+    orig_backup = mcts_mod.MCTS.backup
+
+    def backup(self, leaves):
+        rec.pending = dict(v=self.decisions.v, w=self.stats.w, n=self.stats.n, rewards=self.transitions.rewards,
+                           parents=self.tree.parents, terminal=self.transitions.terminal)
+        return orig_backup(self, leaves)
+    mcts_mod.MCTS.backup = backup
+
+    # capture the Dirichlet draw: dirichlet_noise (mcts/__init__.py:13-24) samples once per search
+    draws = []
+    orig_sample = torch.distributions.Dirichlet.sample
+
+    def sample(self, shape=torch.Size()):
+        d = orig_sample(self, shape)
+        draws.append(d.clone())
+        return d
+    torch.distributions.Dirichlet.sample = sample
+
+    rec.install()
+    try:
+        for move in range(n_moves):
+            rec.sim, rec.rands, rec.ops = 0, [], []
+            rnet.calls = []
+            del draws[:]
+            m = mcts_mod.mcts(worlds, rnet, n_nodes=T)
+            r = m.root()
+            # what MCTSAgent.__call__ does next (mcts/__init__.py:221)
+            actions = torch.distributions.Categorical(logits=r.logits.float()).sample()
+            agent_like = dict(logits=r.logits, prior=r.prior, v=r.v, n_leaves=m.n_leaves(), actions=actions)
+            p = f'm{move}_'
+            out[p + 'dirichlet'] = np_(draws[0])
+            out[p + 'rands'] = np.stack(rec.rands)                                     # (T-1,B,T) f16 bits
+            out[p + 'net0_logits'] = np_(rnet.calls[0]['logits'])                      # f32, initialize
+            out[p + 'net0_v'] = np_(rnet.calls[0]['v'])
+            out[p + 'net_logits'] = np.stack([np_(c['logits'].half()) for c in rnet.calls[1:]])  # (T-1,B,A)
+            out[p + 'net_v'] = np.stack([np_(c['v'].half()) for c in rnet.calls[1:]])
+            out[p + 'net_board'] = np.stack([np_(c['board']) for c in rnet.calls[1:]])  # leaf worlds seen by net
+            out[p + 'net_seats'] = np.stack([np_(c['seats']) for c in rnet.calls[1:]])
+            for k, v in agent_like.items():
+                out[p + 'dec_' + k] = np_(v)
+            out[p + 'root_probs'] = np_(mcuda.root(m._cuda()))                       # before mcts/__init__.py:147's log
+            out[p + 'children'] = np_(m.tree.children); out[p + 'parents'] = np_(m.tree.parents)
+            out[p + 'relation'] = np_(m.tree.relation); out[p + 'n'] = np_(m.stats.n); out[p + 'w'] = np_(m.stats.w)
+            out[p + 'tree_logits'] = np_(m.decisions.logits); out[p + 'tree_v'] = np_(m.decisions.v)
+            out[p + 'rewards'] = np_(m.transitions.rewards); out[p + 'terminal'] = np_(m.transitions.terminal)
+            out[p + 'boards'] = np_(m.worlds.board); out[p + 'seats'] = np_(m.worlds.seats)
+            for kind, sim, d in rec.ops:
+                ops_all.append((move, kind, sim, d))
+            worlds, trans = worlds.step(actions)
+            out[p + 'step_rewards'] = np_(trans.rewards); out[p + 'step_terminal'] = np_(trans.terminal)
+    finally:
+        rec.uninstall()
+        mcts_mod.MCTS.backup = orig_backup
+        torch.distributions.Dirichlet.sample = orig_sample
+    return out, ops_all
+
+
+def gen_search(mcts_mod, hex_, networks, mcuda, out):
+    # (name, S, B, T, width, depth, moves, seed, sims whose op-level tensors are kept, premix moves)
+    configs = [
+        ('search_3x3', 3, 32, 8, 8, 2, 6, 11, (1, 3, 7), 1),
+        ('search_5x5', 5, 64, 16, 16, 4, 8, 12, (1, 5, 10, 15), 8),      # BASELINE config 1
+        ('search_9x9', 9, 64, 64, 32, 2, 3, 13, (1, 20, 63), 27),        # BASELINE config 2's board/T at B=64
+        ('search_13x13', 13, 16, 64, 32, 2, 2, 14, (1, 40, 63), 56),
+    ]
+    for name, S, B, T, width, depth, moves, seed, keep, mix in configs:
+        res, ops = run_search_fixture(mcts_mod, hex_, networks, mcuda, S, B, T, width, depth, moves, seed, set(keep), mix)
+        np.savez_compressed(os.path.join(out, name + '.npz'), **res)
+        opd = {}
+        for i, (move, kind, sim, d) in enumerate(ops):
+            if move > 1:
+                continue
+            for k, v in d.items():
+                opd[f'{kind}_m{move}_s{sim}_{k}'] = v
+        np.savez_compressed(os.path.join(out, name.replace('search', 'ops') + '.npz'), **opd)
+        print(name, os.path.getsize(os.path.join(out, name + '.npz')) // 1024, 'KiB;', 'ops',
+              os.path.getsize(os.path.join(out, name.replace('search', 'ops') + '.npz')) // 1024, 'KiB')
+
+
+# --------------------------------------------------------------------------------------------------------------
+# 4. Toy-environment integration goldens (boardlaw/mcts/tests.py:242-279)
+# --------------------------------------------------------------------------------------------------------------
+def gen_toy(mcts_mod, validation, out):
+    res = {}
+    torch.manual_seed(21)
+    agent = validation.ProxyAgent()
+    m = mcts_mod.mcts(validation.Win.initial(device='cpu'), agent, n_nodes=3)
+    res['win_v'] = np_(m.root().v.float())
+    m = mcts_mod.mcts(validation.WinnerLoser.initial(device='cpu'), agent, n_nodes=3)
+    res['winnerloser_v'] = np_(m.root().v.float())
+    m = mcts_mod.mcts(validation.All.initial(length=3, device='cpu'), agent, n_nodes=15, noise_eps=0.)
+    res['all_v'] = np_(m.root().v.float())
+    m = mcts_mod.mcts(validation.All.initial(n_envs=2, length=3, device='cpu'), agent, n_nodes=15, noise_eps=0.)
+    res['all2_v'] = np_(m.root().v.float())
+    np.savez_compressed(os.path.join(out, 'toy_envs.npz'), **res)
+    print('toy', {k: v.tolist() for k, v in res.items()})
+
+
+# --------------------------------------------------------------------------------------------------------------
+# 5. expf over every binary16 input, as this container's libm computes it (pins the GPU box's libm to ours)
+# --------------------------------------------------------------------------------------------------------------
+def gen_exp(out):
+    import ctypes
+    lib = ctypes.CDLL(os.path.join(ROOT, 'oracle/liboracle.so'))
+    table = np.zeros(65536, np.float32)
+    lib.orc_exp_table(table.ctypes.data_as(ctypes.c_void_p))
+    # cross-check against torch's own f16->f32->exp on CPU for finite inputs is NOT expected to be bit-equal
+    # (torch uses SLEEF); the table is libm's, which is what the reference's cpu.cpp:86 calls.
+    np.savez_compressed(os.path.join(out, 'expf_f16_table.npz'), table=table.view(np.uint32))
+    print('expf table written')
+
+
+if __name__ == '__main__':
+    mcts_mod, hex_, networks, validation, mcuda, hcuda = import_reference()
+    out = HERE if not VARIANT else os.path.join('/tmp', 'golden' + VARIANT)
+    os.makedirs(out, exist_ok=True)
+    gen_hex(hex_, hcuda.module(), out)
+    gen_search(mcts_mod, hex_, networks, mcuda, out)
+    gen_toy(mcts_mod, validation, out)
+    gen_exp(out)
