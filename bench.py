@@ -1,0 +1,199 @@
+"""bench.py -- MCTS simulations/sec on 9x9 Hex, 4096 envs x 64 sims per move (BASELINE.json config 2), per GPU.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+A "step" is one self-play move of the whole batch: MCTSAgent(worlds) -- root evaluation + 63 simulations per env, i.e.
+T = 64 network evaluations per env (SURVEY 8d counts the root as a simulation) -- followed by worlds.step(actions).
+Inputs are synthetic and resident in HBM before the clock starts: Hex.initial pre-mixed with floor(81/3) random legal
+moves (seeded), FCModel 512x4 with default init under manual_seed(0), fp16 autocast in simulate like the reference.
+Multi-GPU: every rank owns an independent shard of 4096 envs and a network replica (self-play has no data-path
+collective; each shard normalises q over its own envs -- "replicas" semantics, SURVEY 8e option 1) => weak scaling.
+
+Prints ONE JSON line (rank 0).  Extra objects:
+  roofline     the dominant kernel (bl_sim_expand: descend+expand+step+observe), algorithmic bytes per launch (model
+               of SURVEY 8d with d,k measured by the kernel's own counters) / its mean duration from HIP events
+               recorded around every launch inside the timed region, vs the 8 TB/s HBM peak.
+  cpu_baseline the reference's own CPU kernels (oracle/_ref, kind "reference") or the C oracle (kind "port") driving
+               the same search on a bounded sample (fewer envs, one move) on this host, single thread.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+BOARD, ENVS, NODES, WIDTH, DEPTH = 9, 4096, 64, 512, 4
+HBM_PEAK_GBS = 8000.0
+
+
+def premix(worlds, moves, gen):
+    """floor(S^2/3) uniformly random legal moves per env; the reference's learning.mix plays 2500."""
+    for _ in range(moves):
+        valid = worlds.valid
+        r = torch.rand(valid.shape, device=valid.device, generator=gen) * valid
+        worlds, _ = worlds.step(r.argmax(-1), check=False)
+    return worlds
+
+
+class TimedExpand:
+    """Wraps the library's bl_sim_expand so that every launch inside the timed region is bracketed by HIP events on
+    the stream it is launched on (torch's current stream)."""
+
+    def __init__(self, lib):
+        self.lib, self.orig = lib, lib.bl_sim_expand
+        self.pairs, self.on = [], False
+
+    def __call__(self, *args):
+        if not self.on:
+            return self.orig(*args)
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        rc = self.orig(*args)
+        b.record()
+        self.pairs.append((a, b))
+        return rc
+
+    def mean_us(self):
+        return 1e3 * float(np.mean([a.elapsed_time(b) for a, b in self.pairs]))
+
+
+def tree_statistics(worlds, net, nodes):
+    """d (policy evaluations / descent), k (expanded-child lookups / descent), Newton iterations / evaluation: measured
+    by the counting variant of the kernel on one untimed search."""
+    from boardlaw_amd.mcts import MCTS
+    m = MCTS(worlds, n_nodes=nodes, count=True)
+    m.initialize(net)
+    for _ in range(nodes - 1):
+        m.simulate(net)
+    c = m.counters.cpu().numpy().astype(np.float64)
+    descents = worlds.n_envs * (nodes - 1)
+    return c[0] / descents, c[1] / descents, c[2] / max(c[0], 1)
+
+
+def expand_bytes_per_env(A, S, d, k):
+    """Algorithmic HBM bytes bl_sim_expand moves per env per launch (terms of SURVEY 8d that belong to this kernel):
+    per visited node children row 2A + logits row 2A + seat 2(4 here) + terminal 1 + rand 2; per expanded child w 2 +
+    n 2; expansion: parent board A + leaf board A + obs 8A + valid A + seats r/w 8 + children/parents/relation 6 +
+    rewards 2S + terminal 1 + leaf id 2 + leaf seat 4."""
+    return d * (4 * A + 5) + 4 * k + (11 * A + 8 + 6 + 2 * S + 1 + 2 + 4)
+
+
+def total_bytes_per_sim(A, S, T, d, k):
+    """SURVEY 8d's whole-path figure: bytes/sim = d(4A+5) + 4k + f(2S+2) + (d+1)(6S+7) + 13A + 6S + 19, f = (T+1)/2."""
+    return d * (4 * A + 5) + 4 * k + (T + 1) / 2 * (2 * S + 2) + (d + 1) * (6 * S + 7) + 13 * A + 6 * S + 19
+
+
+def cpu_baseline(seconds_budget=25.0):
+    """The same search on the host: reference CPU kernels if oracle/_ref is present, else the C oracle."""
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    try:
+        import oracle_lib
+        from cpu_driver import run_cpu_search
+    except Exception as e:  # pragma: no cover
+        return {'value': None, 'unit': 'sims/s', 'cores': 1, 'kind': 'port', 'sample': f'unavailable: {e}'}
+    return run_cpu_search(BOARD, NODES, WIDTH, DEPTH, seconds_budget)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--envs', type=int, default=ENVS, help='envs per GPU (the metric is quoted at 4096)')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    rank = int(os.environ.get('RANK', 0)); world = int(os.environ.get('WORLD_SIZE', 1))
+    local = int(os.environ.get('LOCAL_RANK', 0))
+    assert torch.cuda.is_available(), 'bench.py needs an MI355X; there is no CPU path'
+    torch.cuda.set_device(local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+
+    from boardlaw_amd import _native, networks
+    from boardlaw_amd.hex import Hex
+    from boardlaw_amd.mcts import MCTSAgent
+    lib = _native.lib()
+
+    gen = torch.Generator(device='cuda'); gen.manual_seed(1000 + rank)
+    torch.manual_seed(0)
+    worlds = Hex.initial(args.envs, BOARD)
+    net = networks.FCModel(worlds.obs_space, worlds.action_space, width=WIDTH, depth=DEPTH).cuda()
+    worlds = premix(worlds, BOARD * BOARD // 3, gen)
+    torch.manual_seed(1 + rank)
+    agent = MCTSAgent(net, n_nodes=NODES)
+
+    timer = TimedExpand(lib)
+    lib.bl_sim_expand = timer
+
+    def move(w):
+        d = agent(w)
+        w, _ = w.step(d.actions, check=False)
+        return w
+
+    for _ in range(args.warmup):
+        worlds = move(worlds)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    barrier()
+    timer.on = True
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        worlds = move(worlds)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    timer.on = False
+    if dist is not None:
+        t = torch.tensor([elapsed], device='cuda', dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    sims_total = world * args.envs * NODES * args.steps
+    value = sims_total / elapsed
+
+    if rank == 0:
+        A, S = BOARD * BOARD, 2
+        lib.bl_sim_expand = timer.orig
+        d, k, its = tree_statistics(worlds, net, NODES)
+        kernel_us = timer.mean_us()
+        per_launch = expand_bytes_per_env(A, S, d, k) * args.envs
+        achieved = per_launch / (kernel_us * 1e-6) / 1e9
+        out = {
+            'metric': 'mcts_sims_per_sec', 'value': value, 'unit': 'sims/s', 'n_gpus': world, 'steps': args.steps,
+            'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps, 'higher_is_better': True,
+            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': f'9x9 Hex, {args.envs} envs/GPU x {NODES} sims/move, FCModel {WIDTH}x{DEPTH} fp16 autocast '
+                                   '(BASELINE config 2); step = one self-play move of the batch',
+                       'envs_per_gpu': args.envs, 'nodes': NODES, 'boardsize': BOARD, 'parallelism': f'replicas x{world}',
+                       'd_policy_evals_per_descent': round(d, 3), 'k_child_lookups_per_descent': round(k, 3),
+                       'newton_iters_per_eval': round(its, 3),
+                       'bytes_per_sim_whole_path': round(total_bytes_per_sim(A, S, NODES, d, k), 1),
+                       'hbm_frac_whole_path': total_bytes_per_sim(A, S, NODES, d, k) * value / world / (HBM_PEAK_GBS * 1e9)},
+            'roofline': {'bound': 'hbm', 'kernel': 'bl::sim_expand_kernel', 'achieved': achieved, 'peak': HBM_PEAK_GBS,
+                         'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS, 'traffic': None,
+                         'kernel_us': kernel_us, 'bytes_per_launch': per_launch, 'launches_timed': len(timer.pairs)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline()
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,106 @@
+"""ctypes binding of libboardlaw_amd.so (include/boardlaw_amd.h).
+
+There is deliberately NO fallback: if the library is missing or a call fails this raises, so a GPU run can never
+silently go through PyTorch or the CPU."""
+import ctypes
+import os
+
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIBPATH = os.path.join(HERE, 'libboardlaw_amd.so')
+QRANGE_WORDS = 128
+
+_vp, _i = ctypes.c_void_p, ctypes.c_int
+
+
+class Search(ctypes.Structure):
+    """bl_search_t"""
+    _fields_ = [(k, _vp) for k in ('logits', 'v', 'w', 'n', 'children', 'parents', 'relation', 'rewards', 'terminal',
+                                   'boards', 'seats', 'c_puct', 'qrange', 'exp_table')] + \
+               [('B', _i), ('T', _i), ('boardsize', _i)]
+
+
+SYMBOLS = {
+    'bl_abi_version': (_i, []),
+    'bl_strerror': (ctypes.c_char_p, [_i]),
+    'bl_exp_table_host': (_i, [_vp]),
+    'bl_mcts_qrange': (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
+    'bl_qrange_decode': (_i, [_vp, _vp]),
+    'bl_mcts_descend': (_i, [_vp] * 10 + [_i] * 4 + [_vp, _vp, _vp]),
+    'bl_mcts_root': (_i, [_vp] * 9 + [_i] * 4 + [_vp, _vp]),
+    'bl_mcts_backup': (_i, [_vp] * 7 + [_i] * 3 + [_vp]),
+    'bl_hex_step': (_i, [_vp] * 4 + [_i, _i, _vp]),
+    'bl_hex_observe': (_i, [_vp] * 3 + [_i, _i, _vp]),
+    'bl_sim_expand': (_i, [ctypes.POINTER(Search), _i] + [_vp] * 5 + [_vp]),
+    'bl_sim_expand_counted': (_i, [ctypes.POINTER(Search), _i] + [_vp] * 6 + [_vp]),
+    'bl_sim_backup': (_i, [ctypes.POINTER(Search), _i, _vp, _vp, _i, _vp, _i, _vp]),
+    'bl_sim_root': (_i, [ctypes.POINTER(Search), _i, _vp, _vp]),
+    'bl_sim_init': (_i, [ctypes.POINTER(Search), _vp, _vp, _vp]),
+}
+
+_lib = None
+
+
+class NativeError(RuntimeError):
+    pass
+
+
+def lib():
+    """Loads the library. torch is imported first on purpose: its bundled HIP runtime (soname libamdhip64.so.7) is then
+    the one the library binds to, so stream handles and device pointers from torch are valid inside it."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIBPATH):
+            raise NativeError(f'{LIBPATH} is missing: run `python -m boardlaw_amd.build` (needs hipcc). '
+                              'boardlaw_amd has no CPU or PyTorch fallback for its kernels.')
+        L = ctypes.CDLL(LIBPATH)
+        for name, (res, args) in SYMBOLS.items():
+            f = getattr(L, name)
+            f.restype, f.argtypes = res, args
+        _lib = L
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        raise NativeError(f'libboardlaw_amd: {lib().bl_strerror(rc).decode()} (code {rc})')
+
+
+def stream(device=None):
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def ptr(t):
+    return t.data_ptr()
+
+
+def require_device(*tensors):
+    devs = {t.device for t in tensors}
+    if len(devs) != 1:
+        raise AssertionError('Inputs span multiple devices')
+    dev = devs.pop()
+    if dev.type != 'cuda':
+        raise NativeError('boardlaw_amd kernels run on an MI355X only: tensors must live on a cuda (HIP) device, '
+                          f'got {dev}. There is no CPU fallback.')
+    return dev
+
+
+_exp_tables = {}
+
+
+def exp_table(device):
+    """pi = expf(logit) for all 65536 binary16 patterns, from the host libm (cpu.cpp:86), uploaded once per device."""
+    key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+    if key not in _exp_tables:
+        host = torch.empty(65536, dtype=torch.float32)
+        check(lib().bl_exp_table_host(host.data_ptr()))
+        _exp_tables[key] = host.to(device)
+    return _exp_tables[key]
+
+
+def qrange_decode(state):
+    host = state.detach().cpu().contiguous()
+    out = torch.empty(2, dtype=torch.float32)
+    check(lib().bl_qrange_decode(host.data_ptr(), out.data_ptr()))
+    return out

@@ -1,0 +1,804 @@
+// bl_kernels.hip -- gfx950 (MI355X, CDNA4) kernels for boardlaw's vectorised-MCTS hot path.
+//
+// Written for 64-wide wavefronts: every kernel assigns a GROUP of G lanes (G in {8,16,32,64}, chosen by the host
+// from B and A) to one env, so a wave carries 64/G envs.  The lanes of a group stride the action axis, which makes
+// every children[b,t,:] / logits[b,t,:] row a coalesced burst; the per-action Newton terms are staged in LDS and the
+// group's lane 0 folds them in the reference's serial order (float addition is not associative and parity is
+// bit-exact: see DESIGN.md "Exact arithmetic").  The reference (boardlaw/mcts/cpp/cuda.cu) uses one THREAD per env
+// in 8-thread blocks, i.e. 8 of 64 lanes and a row stride of T*A*2 bytes between neighbouring lanes.
+//
+// Arithmetic contract: IEEE binary32, RNE, no contraction (-ffp-contract=off and the pragma below), correctly
+// rounded division (hipcc default), denormals kept; expf through the caller's 65536-entry table (host libm).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <math.h>
+#include <string.h>
+#include "../../include/boardlaw_amd.h"
+
+#pragma clang fp contract(off)
+
+#define BL_QSLOTS 64          // qrange state: 64 slots x {~enc(min), enc(max)}
+#define BL_WAVE 64
+
+namespace bl {
+
+typedef _Float16 f16_t;
+__device__ __forceinline__ float h2f(uint16_t b) { return (float)__builtin_bit_cast(f16_t, b); }
+__device__ __forceinline__ uint16_t f2h(float f) { return __builtin_bit_cast(uint16_t, (f16_t)f); }
+
+// order-preserving float <-> u32
+__host__ __device__ __forceinline__ uint32_t enc(float f) {
+    uint32_t b = __builtin_bit_cast(uint32_t, f);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__host__ __device__ __forceinline__ float dec(uint32_t u) {
+    uint32_t b = (u & 0x80000000u) ? (u & 0x7fffffffu) : ~u;
+    return __builtin_bit_cast(float, b);
+}
+
+template <int G> __device__ __forceinline__ int gsum(int x) {
+#pragma unroll
+    for (int m = G / 2; m > 0; m >>= 1) x += __shfl_xor(x, m, G);
+    return x;
+}
+template <int G> __device__ __forceinline__ float gmaxf(float x) {
+#pragma unroll
+    for (int m = G / 2; m > 0; m >>= 1) x = fmaxf(x, __shfl_xor(x, m, G));
+    return x;
+}
+template <int G> __device__ __forceinline__ uint32_t gmaxu(uint32_t x) {
+#pragma unroll
+    for (int m = G / 2; m > 0; m >>= 1) { uint32_t y = __shfl_xor((int)x, m, G); x = x > y ? x : y; }
+    return x;
+}
+
+// View of the reference's `struct MCTS` (boardlaw/mcts/cpp/common.h:25-33) plus what transition_q needs.
+struct Tree {
+    const uint16_t* logits;   // (B,T,A) f16
+    const uint16_t* w;        // (B,T,S) f16
+    const int16_t* n;         // (B,T)
+    const uint16_t* c_puct;   // (B) f16
+    const void* seats;        // (B,T) i16 (reference struct) or i32 (worlds.seats, fused path)
+    const uint8_t* terminal;  // (B,T)
+    const int16_t* children;  // (B,T,A)
+    const uint32_t* qrange;   // BL_QSLOTS x 2
+    const float* exp_table;   // 65536
+    int B, T, A, S;
+    int seats_i32;
+};
+
+__device__ __forceinline__ int load_seat(const Tree& m, long i) {
+    return m.seats_i32 ? ((const int32_t*)m.seats)[i] : (int)((const int16_t*)m.seats)[i];
+}
+
+// Reduce the 64 qrange slots: every lane of the wave returns {lo, hi}.  transition_q, cuda.cu:101-105.
+__device__ __forceinline__ void load_qrange(const uint32_t* qr, float& lo, float& hi) {
+    const int lane = threadIdx.x & 63;
+    uint32_t a = qr[2 * lane], b = qr[2 * lane + 1];
+    a = gmaxu<64>(a); b = gmaxu<64>(b);
+    lo = dec(~a); hi = dec(b);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// policy(): cuda.cu:70-99 + newton_search cuda.cu:35-68, for the group's env b at node t.
+// On return terms[a].x == prob(a) (cuda.cu:23-25) for the final alpha, lch[a] == children[b,t,a].
+// `go` is group-uniform; groups with go == false only keep the wave's barriers company.
+// ------------------------------------------------------------------------------------------------------------------
+template <int G, int K, bool COUNT>
+__device__ __forceinline__ void policy_eval(const Tree& m, int b, int t, bool go, int gl, float lo, float rden,
+                                            float2* terms, int16_t* lch, unsigned long long* counters) {
+    const int A = m.A, T = m.T, S = m.S;
+    float top[K], q[K];
+    int Nloc = 0, nch = 0;
+    const long node = (long)b * T + t;
+    const long row = node * A;
+    int seat = go ? load_seat(m, node) : 0;
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+        const int a = k * G + gl;
+        float pi = 0.f, qa = 0.f;
+        if (go && a < A) {
+            const int child = m.children[row + a];
+            pi = m.exp_table[m.logits[row + a]];
+            lch[a] = (int16_t)child;
+            if (child > -1) {
+                const long i = (long)b * T + child;
+                const float wv = h2f(m.w[i * S + seat]);
+                const int nv = m.n[i];
+                const float q32 = wv / ((float)nv + 1.e-4f);
+                qa = h2f(f2h((q32 - lo) / rden));
+                Nloc += nv;
+                nch++;
+            } else {
+                Nloc += 1;
+            }
+        }
+        top[k] = pi; q[k] = qa;
+    }
+    const int N = gsum<G>(Nloc);
+    const float lam = go ? (h2f(m.c_puct[b]) * (float)N) / (float)(unsigned)(N + A) : 0.f;
+    float alpha = 0.f;
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+        top[k] = lam * top[k];
+        if (k * G + gl < A) alpha = fmaxf(alpha, q[k] + fmaxf(top[k], 1.e-4f));
+    }
+    alpha = gmaxf<G>(alpha);
+
+    float err = INFINITY;
+    bool conv = !go;      // group-uniform
+    bool broke = !go;
+    int iters = 0;
+    for (int it = 0; it < 100; it++) {
+        if (!__any(!conv)) break;
+        if (!conv) {
+#pragma unroll
+            for (int k = 0; k < K; k++) {
+                const int a = k * G + gl;
+                if (a < A) {
+                    const float bot = alpha - q[k];
+                    terms[a] = make_float2(top[k] / bot, (-top[k]) / (bot * bot));
+                }
+            }
+        }
+        __syncthreads();
+        float Ssum = 0.f, gsum_ = 0.f;
+        if (!conv && gl == 0) {
+            const float4* t4 = (const float4*)terms;
+            int a = 0;
+#pragma unroll 8
+            for (; a + 1 < A; a += 2) {
+                const float4 x = t4[a >> 1];
+                Ssum += x.x; gsum_ += x.y;
+                Ssum += x.z; gsum_ += x.w;
+            }
+            if (a < A) { const float2 x = terms[a]; Ssum += x.x; gsum_ += x.y; }
+        }
+        Ssum = __shfl(Ssum, 0, G);
+        gsum_ = __shfl(gsum_, 0, G);
+        if (!conv) {
+            iters++;
+            const float ne = Ssum - 1.f;
+            if ((ne < 1e-3f) || (err == ne)) { conv = true; broke = true; }
+            else { alpha -= ne / gsum_; err = ne; }
+        }
+        __syncthreads();
+    }
+    // 100 iterations without a break leave alpha updated past the last evaluated terms (cuda.cu:48-65): refresh.
+    if (__any(!broke)) {
+        if (!broke) {
+#pragma unroll
+            for (int k = 0; k < K; k++) {
+                const int a = k * G + gl;
+                if (a < A) { const float bot = alpha - q[k]; terms[a] = make_float2(top[k] / bot, 0.f); }
+            }
+        }
+        __syncthreads();
+    }
+    if (COUNT && go) {
+        const int nc = gsum<G>(nch);
+        if (gl == 0) {
+            atomicAdd(&counters[0], 1ull);
+            atomicAdd(&counters[1], (unsigned long long)nc);
+            atomicAdd(&counters[2], (unsigned long long)iters);
+        }
+    }
+}
+
+// descend_kernel's per-env loop, cuda.cu:138-182.  Returns group-uniform (parent, action, next) where next ==
+// children[b,parent,action] (-1 for an unexpanded edge, a terminal node's id otherwise).
+template <int G, int K, bool COUNT>
+__device__ __forceinline__ void descend_group(const Tree& m, int b, bool act, int gl, const uint16_t* rands,
+                                              float2* terms, int16_t* lch, unsigned long long* counters,
+                                              int& parent_out, int& action_out, int& next_out) {
+    float lo, hi;
+    load_qrange(m.qrange, lo, hi);
+    const float rden = hi - lo + 1.e-4f;
+    int t = 0, parent = 0, action = -1;
+    while (true) {
+        bool go = act && (t != -1);
+        if (go) go = !m.terminal[(long)b * m.T + t];
+        if (!__any(go)) break;
+        policy_eval<G, K, COUNT>(m, b, t, go, gl, lo, rden, terms, lch, counters);
+        int nxt = -1;
+        if (go && gl == 0) {
+            // inverse-CDF walk in ascending a, cuda.cu:157-176
+            const float r = h2f(rands[(long)b * m.T + t]);
+            float total = 0.f;
+            int valid = -1;
+            action = -1;
+            for (int a = 0; a < m.A; a++) {
+                const float p = terms[a].x;
+                total += p;
+                if ((p > 0) && (total >= r)) { action = a; break; }
+                else if (p > 0) { valid = a; }
+            }
+            action = (action >= 0) ? action : valid;
+            nxt = (action >= 0) ? (int)lch[action] : -1;
+        }
+        action = __shfl(action, 0, G);
+        nxt = __shfl(nxt, 0, G);
+        if (go) {
+            parent = t;
+            t = nxt;
+            if (action < 0) act = false;   // reference would index children[b][t][-1]; unreachable with a finite logit
+        }
+        __syncthreads();
+    }
+    parent_out = parent; action_out = action; next_out = t;
+}
+
+template <int G, int K, bool COUNT>
+__global__ void __launch_bounds__(BL_WAVE) descend_kernel(Tree m, const uint16_t* rands, int16_t* parents,
+                                                          int16_t* actions, int lds_terms, unsigned long long* counters) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int grp = threadIdx.x / G, gl = threadIdx.x % G;
+    const int b = blockIdx.x * (BL_WAVE / G) + grp;
+    char* base = smem + (size_t)grp * (lds_terms + ((2 * m.A + 15) & ~15));
+    float2* terms = (float2*)base;
+    int16_t* lch = (int16_t*)(base + lds_terms);
+    int parent, action, nxt;
+    descend_group<G, K, COUNT>(m, b, b < m.B, gl, rands, terms, lch, counters, parent, action, nxt);
+    if (b < m.B && gl == 0) { parents[b] = (int16_t)parent; actions[b] = (int16_t)action; }
+}
+
+// root_kernel, cuda.cu:107-118
+template <int G, int K>
+__global__ void __launch_bounds__(BL_WAVE) root_kernel(Tree m, uint16_t* probs, int lds_terms) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int grp = threadIdx.x / G, gl = threadIdx.x % G;
+    const int b = blockIdx.x * (BL_WAVE / G) + grp;
+    char* base = smem + (size_t)grp * (lds_terms + ((2 * m.A + 15) & ~15));
+    float2* terms = (float2*)base;
+    int16_t* lch = (int16_t*)(base + lds_terms);
+    float lo, hi;
+    load_qrange(m.qrange, lo, hi);
+    const bool go = b < m.B;
+    policy_eval<G, K, false>(m, b, 0, go, gl, lo, hi - lo + 1.e-4f, terms, lch, nullptr);
+    if (go) for (int a = gl; a < m.A; a += G) probs[(long)b * m.A + a] = f2h(terms[a].x);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// transition_q's range.  One thread per (b,t) node; per-wave reduce; one conditional atomic pair per wave.
+// ------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void qrange_publish(uint32_t* qr, uint32_t nmin, uint32_t vmax, int slot) {
+    nmin = gmaxu<64>(nmin); vmax = gmaxu<64>(vmax);
+    if ((threadIdx.x & 63) == 0) {
+        uint32_t* p = qr + 2 * slot;
+        if (nmin > __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(p, nmin);
+        if (vmax > __hip_atomic_load(p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(p + 1, vmax);
+    }
+}
+
+__global__ void __launch_bounds__(256) qrange_kernel(const uint16_t* w, const int16_t* n, long nodes, int S, uint32_t* qr) {
+    uint32_t nmin = 0, vmax = 0;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nodes; i += (long)gridDim.x * blockDim.x) {
+        const float den = (float)n[i] + 1.e-4f;
+        for (int s = 0; s < S; s++) {
+            const uint32_t e = enc(h2f(w[i * S + s]) / den);
+            nmin = max(nmin, ~e); vmax = max(vmax, e);
+        }
+    }
+    qrange_publish(qr, nmin, vmax, (blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64) % BL_QSLOTS);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// backup_kernel, cuda.cu:205-236: one lane per (env, seat); lane s == 0 also owns n.
+// n += 1 sits inside the seat loop in the reference, so a visit adds S to n (int16 wrap-around kept).
+// w = rn16(f32(w) + f32(rn16(v))): c10::Half += float rounds v to f16 first.
+// ------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void backup_walk(const uint16_t* rewards, const int16_t* parents, const uint8_t* terminal,
+                                            uint16_t* w, int16_t* n, long envbase, int S, int s, int leaf, float v) {
+    int cur = leaf;
+    while (cur != -1) {
+        const long i = envbase + cur;
+        if (terminal[i]) v = 0.f;
+        v += h2f(rewards[i * S + s]);
+        if (s == 0) n[i] = (int16_t)(n[i] + S);
+        w[i * S + s] = f2h(h2f(w[i * S + s]) + h2f(f2h(v)));
+        cur = parents[i];
+    }
+}
+
+__global__ void __launch_bounds__(256) backup_kernel(const uint16_t* v, uint16_t* w, int16_t* n, const uint16_t* rewards,
+                                                     const int16_t* parents, const uint8_t* terminal,
+                                                     const int16_t* leaves, int B, int T, int S) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long)B * S) return;
+    const int b = (int)(idx / S), s = (int)(idx % S);
+    const int leaf = leaves[b];
+    const long envbase = (long)b * T;
+    backup_walk(rewards, parents, terminal, w, n, envbase, S, s, leaf, h2f(v[(envbase + leaf) * S + s]));
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Hex.  Cell codes and rules: boardlaw/hex/cpp/cuda.cu:8-16,76-137; flood cuda.cu:18-74.
+// ------------------------------------------------------------------------------------------------------------------
+enum { EMPTY = 0, BLACK, WHITE, TOP, BOT, LEFT, RIGHT, MARK = 0xff };
+
+// One group steps one board held in LDS `cells` (A bytes).  Returns the winner's sign in `win` (0 none, +1 black
+// wins => rewards (+1,-1), -1 white wins => (-1,+1)).  Group-uniform control flow; `go` false groups idle.
+template <int G>
+__device__ __forceinline__ int hex_step_group(uint8_t* cells, int S, int seat, int action, bool go, int gl) {
+    const int A = S * S;
+    const float invS = 1.0f / (float)S;
+    int label = 0, win = 0, start = 0;
+    uint8_t plain = 0;
+    if (go && gl == 0) {
+        const int qd = (int)(((float)action + 0.5f) * invS), rm = action - qd * S;
+        const int row = seat == 0 ? qd : rm, col = seat == 0 ? rm : qd;   // white plays transposed, cuda.cu:88-91
+        unsigned adj = 0;
+        const int dr[6] = {-1, -1, 0, 0, +1, +1}, dc[6] = {0, +1, -1, +1, -1, 0};
+#pragma unroll
+        for (int k = 0; k < 6; k++) {
+            const int r = row + dr[k], c = col + dc[k];
+            int code;
+            if (r < 0) code = TOP; else if (r >= S) code = BOT; else if (c < 0) code = LEFT; else if (c >= S) code = RIGHT;
+            else code = cells[r * S + c];
+            adj |= 1u << code;
+        }
+        const bool aT = adj & (1u << TOP), aB = adj & (1u << BOT), aL = adj & (1u << LEFT), aR = adj & (1u << RIGHT);
+        if (seat) { if (aL && aR) win = -1; label = aL ? LEFT : (aR ? RIGHT : WHITE); plain = WHITE; }
+        else      { if (aT && aB) win = +1; label = aT ? TOP : (aB ? BOT : BLACK); plain = BLACK; }
+        start = row * S + col;
+        // the reference writes the plain colour then floods from it; a flood relabels the start cell too
+        cells[start] = (label >= TOP) ? (uint8_t)MARK : plain;
+    }
+    label = __shfl(label, 0, G); win = __shfl(win, 0, G);
+    plain = (uint8_t)__shfl((int)plain, 0, G);
+    const bool flooding = go && label >= TOP;
+    __syncthreads();
+    // Relabel the 6-connected component of `plain` cells containing the start cell (== the BFS of cuda.cu:18-74):
+    // sweep until no plain cell touches a MARKed one.
+    while (true) {
+        bool changed = false;
+        if (flooding) {
+            for (int a = gl; a < A; a += G) {
+                if (cells[a] != plain) continue;
+                const int r = (int)(((float)a + 0.5f) * invS), c = a - r * S;
+                bool hit = false;
+                if (r > 0) { hit |= cells[a - S] == MARK; if (c < S - 1) hit |= cells[a - S + 1] == MARK; }
+                if (c > 0) hit |= cells[a - 1] == MARK;
+                if (c < S - 1) hit |= cells[a + 1] == MARK;
+                if (r < S - 1) { hit |= cells[a + S] == MARK; if (c > 0) hit |= cells[a + S - 1] == MARK; }
+                if (hit) { cells[a] = MARK; changed = true; }
+            }
+        }
+        __syncthreads();
+        if (!__any(changed)) break;
+    }
+    if (flooding) for (int a = gl; a < A; a += G) if (cells[a] == MARK) cells[a] = (uint8_t)label;
+    __syncthreads();
+    return win;
+}
+
+template <int G>
+__global__ void __launch_bounds__(BL_WAVE) hex_step_kernel(uint8_t* board, const int32_t* seats, const int32_t* actions,
+                                                           float* rewards, int B, int S) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int A = S * S, grp = threadIdx.x / G, gl = threadIdx.x % G;
+    const int b = blockIdx.x * (BL_WAVE / G) + grp;
+    const bool go = b < B;
+    uint8_t* cells = (uint8_t*)smem + (size_t)grp * ((A + 15) & ~15);
+    uint8_t* src = board + (long)b * A;
+    if (go) for (int a = gl; a < A; a += G) cells[a] = src[a];
+    __syncthreads();
+    const int win = hex_step_group<G>(cells, S, go ? seats[b] : 0, go ? actions[b] : 0, go, gl);
+    if (go) {
+        for (int a = gl; a < A; a += G) src[a] = cells[a];
+        if (gl == 0) { rewards[2 * b] = (float)win; rewards[2 * b + 1] = (float)(-win); }
+    }
+}
+
+// observe, cuda.cu:154-195: mover sees itself in channel 0, playing top-to-bottom.
+__device__ __forceinline__ int color_of(int c) { return (c == BLACK || c == TOP || c == BOT) ? 0 : ((c == WHITE || c == LEFT || c == RIGHT) ? 1 : 2); }
+
+__global__ void __launch_bounds__(256) hex_observe_kernel(const uint8_t* board, const int32_t* seats, float2* obs, long cells, int S) {
+    const int A = S * S;
+    const float invS = 1.0f / (float)S;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < cells; idx += (long)gridDim.x * blockDim.x) {
+        const long b = idx / A;
+        const int a = (int)(idx - b * A);
+        const int i = (int)(((float)a + 0.5f) * invS), j = a - i * S;
+        const bool flip = seats[b] == 1;
+        const int color = color_of(board[b * A + (flip ? j * S + i : a)]);
+        float2 o = make_float2(0.f, 0.f);
+        if (color < 2) { if ((flip ? 1 - color : color) == 0) o.x = 1.f; else o.y = 1.f; }
+        obs[idx] = o;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Fused simulation step for Hex: mcts/__init__.py:113-129 + hex/__init__.py:148-195.
+// ------------------------------------------------------------------------------------------------------------------
+struct Search {
+    uint16_t* logits; uint16_t* v; uint16_t* w; int16_t* n; int16_t* children; int16_t* parents; int16_t* relation;
+    uint16_t* rewards; uint8_t* terminal; uint8_t* boards; int32_t* seats; const uint16_t* c_puct; uint32_t* qrange;
+    const float* exp_table; int B, T, S;
+};
+
+template <int G, int K, bool COUNT>
+__global__ void __launch_bounds__(BL_WAVE) sim_expand_kernel(Search s, int sim, const uint16_t* rands, int16_t* leaves_out,
+                                                             float2* obs_out, uint8_t* valid_out, int32_t* leaf_seats_out,
+                                                             int lds_terms, unsigned long long* counters) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int S = s.S, A = S * S, T = s.T;
+    const int grp = threadIdx.x / G, gl = threadIdx.x % G;
+    const int b = blockIdx.x * (BL_WAVE / G) + grp;
+    const bool act = b < s.B;
+    const int lds_ch = (2 * A + 15) & ~15, lds_cells = (A + 15) & ~15;
+    char* base = smem + (size_t)grp * (lds_terms + lds_ch + lds_cells);
+    float2* terms = (float2*)base;
+    int16_t* lch = (int16_t*)(base + lds_terms);
+    uint8_t* cells = (uint8_t*)(base + lds_terms + lds_ch);
+
+    Tree m;
+    m.logits = s.logits; m.w = s.w; m.n = s.n; m.c_puct = s.c_puct; m.seats = s.seats; m.terminal = s.terminal;
+    m.children = s.children; m.qrange = s.qrange + 2 * BL_QSLOTS * sim; m.exp_table = s.exp_table;
+    m.B = s.B; m.T = T; m.A = A; m.S = 2; m.seats_i32 = 1;
+
+    int parent, action, nxt;
+    descend_group<G, K, COUNT>(m, b, act, gl, rands, terms, lch, counters, parent, action, nxt);
+    if (action < 0) action = 0;
+
+    // leaves = children[envs, parents, actions]; leaves[leaves == -1] = sim   (mcts/__init__.py:117-122)
+    const int leaf = (nxt == -1) ? sim : nxt;
+    const long envbase = (long)b * T;
+    int seat = 0;
+    if (act) {
+        if (gl == 0) {
+            s.children[(envbase + parent) * A + action] = (int16_t)leaf;
+            s.parents[envbase + leaf] = (int16_t)parent;
+            s.relation[envbase + leaf] = (int16_t)action;
+        }
+        seat = s.seats[envbase + parent];
+        const uint8_t* src = s.boards + (envbase + parent) * A;
+        for (int a = gl; a < A; a += G) cells[a] = src[a];
+    }
+    __syncthreads();
+    const int win = hex_step_group<G>(cells, S, seat, action, act, gl);
+    if (!act) return;
+    // Hex.step tail, hex/__init__.py:183-190
+    const bool term = win != 0;
+    const int new_seat = term ? 0 : 1 - seat;
+    uint8_t* dst = s.boards + (envbase + leaf) * A;
+    const float invS = 1.0f / (float)S;
+    const bool flip = new_seat == 1;
+    for (int a = gl; a < A; a += G) {
+        const uint8_t c = term ? (uint8_t)0 : cells[a];
+        dst[a] = c;
+    }
+    for (int a = gl; a < A; a += G) {
+        const int i = (int)(((float)a + 0.5f) * invS), j = a - i * S;
+        const int color = term ? 2 : color_of(cells[flip ? j * S + i : a]);
+        float2 o = make_float2(0.f, 0.f);
+        if (color < 2) { if ((flip ? 1 - color : color) == 0) o.x = 1.f; else o.y = 1.f; }
+        obs_out[(long)b * A + a] = o;
+        valid_out[(long)b * A + a] = color == 2;
+    }
+    if (gl == 0) {
+        s.seats[envbase + leaf] = new_seat;
+        s.terminal[envbase + leaf] = term;
+        // transition.rewards.half(): +-1 and 0 are exact in f16
+        s.rewards[(envbase + leaf) * 2 + 0] = f2h((float)win);
+        s.rewards[(envbase + leaf) * 2 + 1] = f2h((float)(-win));
+        leaves_out[b] = (int16_t)leaf;
+        leaf_seats_out[b] = new_seat;
+    }
+}
+
+// mcts/__init__.py:135-140: store logits/v for the leaf, back up, then reduce next sim's q-range.  16 lanes per env.
+__global__ void __launch_bounds__(BL_WAVE) sim_backup_kernel(Search s, int sim, const int16_t* leaves, const void* leaf_logits,
+                                                            int logits_f16, const void* leaf_v, int v_f16) {
+    constexpr int G = 16;
+    const int S = s.S, A = S * S, T = s.T;
+    const int grp = threadIdx.x / G, gl = threadIdx.x % G;
+    const int b = blockIdx.x * (BL_WAVE / G) + grp;
+    const bool act = b < s.B;
+    const long envbase = (long)b * T;
+    uint32_t nmin = 0, vmax = 0;
+    if (act) {
+        const int leaf = leaves[b];
+        uint16_t* dst = s.logits + (envbase + leaf) * A;
+        if (logits_f16) { const uint16_t* src = (const uint16_t*)leaf_logits + (long)b * A; for (int a = gl; a < A; a += G) dst[a] = src[a]; }
+        else { const float* src = (const float*)leaf_logits + (long)b * A; for (int a = gl; a < A; a += G) dst[a] = f2h(src[a]); }
+        if (gl < 2) {
+            const uint16_t vb = v_f16 ? ((const uint16_t*)leaf_v)[2 * b + gl] : f2h(((const float*)leaf_v)[2 * b + gl]);
+            s.v[(envbase + leaf) * 2 + gl] = vb;
+            backup_walk(s.rewards, s.parents, s.terminal, s.w, s.n, envbase, 2, gl, leaf, h2f(vb));
+        }
+    }
+    __syncthreads();   // workgroup-scope release/acquire: the walk's stores are visible to the scan below
+    if (act) {
+        for (int e = gl; e < T; e += G) {
+            const float den = (float)s.n[envbase + e] + 1.e-4f;
+            const uint32_t e0 = enc(h2f(s.w[(envbase + e) * 2]) / den), e1 = enc(h2f(s.w[(envbase + e) * 2 + 1]) / den);
+            nmin = max(nmin, max(~e0, ~e1)); vmax = max(vmax, max(e0, e1));
+        }
+    }
+    qrange_publish(s.qrange + 2 * BL_QSLOTS * (sim + 1), nmin, vmax, blockIdx.x % BL_QSLOTS);
+}
+
+__global__ void __launch_bounds__(256) sim_replicate_kernel(Search s, const uint8_t* root_board, const int32_t* root_seats) {
+    const int A = s.S * s.S;
+    const long total = (long)s.B * s.T * A;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const long node = idx / A;
+        const int a = (int)(idx - node * A);
+        const long b = node / s.T;
+        s.boards[idx] = root_board[b * A + a];
+        if (a == 0) s.seats[node] = root_seats[b];
+    }
+    // descend #1 sees the untouched stats: every q is 0/1e-4 = 0, so its range is {0, 0}
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        s.qrange[2 * BL_QSLOTS * 1 + 0] = ~enc(0.f);
+        s.qrange[2 * BL_QSLOTS * 1 + 1] = enc(0.f);
+    }
+}
+
+}  // namespace bl
+
+// =====================================================================================================================
+// C ABI
+// =====================================================================================================================
+using namespace bl;
+
+static int pick_group(int B, int A) {
+    // Smallest group that keeps <= 16 actions per lane, widened while the launch has too few waves to cover the
+    // chip's 1024 SIMDs (256 CUs x 4): lanes idle in the serial fold are cheaper than idle SIMDs.
+    int G = 8;
+    while (G < 64 && (A + G - 1) / G > 16) G *= 2;
+    while (G < 64 && (long)B * G / 64 < 1024) G *= 2;
+    return G;
+}
+
+static int pick_k(int A, int G) {
+    const int need = (A + G - 1) / G;
+    const int ks[4] = {2, 6, 12, 16};
+    for (int i = 0; i < 4; i++) if (need <= ks[i]) return ks[i];
+    return -1;
+}
+
+static int check_launch() { return hipGetLastError() == hipSuccess ? BL_OK : BL_ELAUNCH; }
+
+#define BL_DISPATCH_GK(G, K, CALL)                                                                   \
+    switch ((G) * 100 + (K)) {                                                                       \
+        case 802: { CALL(8, 2); } break;   case 806: { CALL(8, 6); } break;                           \
+        case 812: { CALL(8, 12); } break;  case 816: { CALL(8, 16); } break;                          \
+        case 1602: { CALL(16, 2); } break; case 1606: { CALL(16, 6); } break;                         \
+        case 1612: { CALL(16, 12); } break; case 1616: { CALL(16, 16); } break;                       \
+        case 3202: { CALL(32, 2); } break; case 3206: { CALL(32, 6); } break;                         \
+        case 3212: { CALL(32, 12); } break; case 3216: { CALL(32, 16); } break;                       \
+        case 6402: { CALL(64, 2); } break; case 6406: { CALL(64, 6); } break;                         \
+        case 6412: { CALL(64, 12); } break; case 6416: { CALL(64, 16); } break;                       \
+        default: return BL_ETOOBIG;                                                                  \
+    }
+
+extern "C" {
+
+int bl_abi_version(void) { return 1; }
+
+const char* bl_strerror(int code) {
+    switch (code) {
+        case BL_OK: return "ok";
+        case BL_EINVAL: return "invalid argument (null pointer or non-positive size)";
+        case BL_ETOOBIG: return "size beyond kernel limits (A <= 1024, T <= 32767, S <= 8, boardsize <= 32)";
+        case BL_ELAUNCH: return "HIP kernel launch failed";
+        default: return "unknown error";
+    }
+}
+
+int bl_exp_table_host(float* t) {
+    if (!t) return BL_EINVAL;
+    for (uint32_t i = 0; i < 65536; i++) {
+        uint16_t h = (uint16_t)i;
+        // binary16 -> binary32 (exact)
+        uint32_t sign = (uint32_t)(h & 0x8000u) << 16, e = (h >> 10) & 0x1f, mnt = h & 0x3ffu, bits;
+        if (e == 0) {
+            if (mnt == 0) bits = sign;
+            else { int sh = -1; do { sh++; mnt <<= 1; } while (!(mnt & 0x400u)); bits = sign | ((uint32_t)(112 - sh) << 23) | ((mnt & 0x3ffu) << 13); }
+        } else if (e == 31) bits = sign | 0x7f800000u | (mnt << 13);
+        else bits = sign | ((e + 112) << 23) | (mnt << 13);
+        float x; memcpy(&x, &bits, 4);
+        t[i] = expf(x);
+    }
+    return BL_OK;
+}
+
+int bl_qrange_decode(const uint32_t* st, float* mm) {
+    if (!st || !mm) return BL_EINVAL;
+    uint32_t a = 0, b = 0;
+    for (int i = 0; i < BL_QSLOTS; i++) { if (st[2 * i] > a) a = st[2 * i]; if (st[2 * i + 1] > b) b = st[2 * i + 1]; }
+    mm[0] = dec(~a); mm[1] = dec(b);
+    return BL_OK;
+}
+
+int bl_mcts_qrange(const void* w, const int16_t* n, int B, int T, int S, uint32_t* st, bl_stream_t stream) {
+    if (!w || !n || !st || B <= 0 || T <= 0 || S <= 0) return BL_EINVAL;
+    hipStream_t hs = (hipStream_t)stream;
+    if (hipMemsetAsync(st, 0, 2 * BL_QSLOTS * sizeof(uint32_t), hs) != hipSuccess) return BL_ELAUNCH;
+    const long nodes = (long)B * T;
+    int blocks = (int)((nodes + 255) / 256); if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(qrange_kernel, dim3(blocks), dim3(256), 0, hs, (const uint16_t*)w, n, nodes, S, st);
+    return check_launch();
+}
+
+static int tree_check(const void* logits, const void* w, const void* n, const void* c, const void* seats, const void* term,
+                      const void* ch, const void* qr, const void* et, int B, int T, int A, int S) {
+    if (!logits || !w || !n || !c || !seats || !term || !ch || !qr || !et || B <= 0 || T <= 0 || A <= 0 || S <= 0) return BL_EINVAL;
+    if (A > 1024 || T > 32767 || S > 8) return BL_ETOOBIG;
+    return BL_OK;
+}
+
+int bl_mcts_descend(const void* logits, const void* w, const int16_t* n, const void* c_puct, const int16_t* seats,
+                    const uint8_t* terminal, const int16_t* children, const void* rands, const uint32_t* qr,
+                    const float* exp_table, int B, int T, int A, int S, int16_t* parents, int16_t* actions,
+                    bl_stream_t stream) {
+    int rc = tree_check(logits, w, n, c_puct, seats, terminal, children, qr, exp_table, B, T, A, S);
+    if (rc) return rc;
+    if (!rands || !parents || !actions) return BL_EINVAL;
+    Tree m{(const uint16_t*)logits, (const uint16_t*)w, n, (const uint16_t*)c_puct, seats, terminal, children, qr,
+           exp_table, B, T, A, S, 0};
+    const int G = pick_group(B, A), K = pick_k(A, G);
+    const int lds_terms = (8 * A + 15) & ~15;
+    const int per = lds_terms + ((2 * A + 15) & ~15);
+    const int blocks = (B + 64 / G - 1) / (64 / G);
+#define CALL(g, k) hipLaunchKernelGGL((descend_kernel<g, k, false>), dim3(blocks), dim3(64), (size_t)per * (64 / g), \
+                                      (hipStream_t)stream, m, (const uint16_t*)rands, parents, actions, lds_terms, nullptr)
+    BL_DISPATCH_GK(G, K, CALL)
+#undef CALL
+    return check_launch();
+}
+
+int bl_mcts_root(const void* logits, const void* w, const int16_t* n, const void* c_puct, const int16_t* seats,
+                 const uint8_t* terminal, const int16_t* children, const uint32_t* qr, const float* exp_table,
+                 int B, int T, int A, int S, void* probs, bl_stream_t stream) {
+    int rc = tree_check(logits, w, n, c_puct, seats, terminal, children, qr, exp_table, B, T, A, S);
+    if (rc) return rc;
+    if (!probs) return BL_EINVAL;
+    Tree m{(const uint16_t*)logits, (const uint16_t*)w, n, (const uint16_t*)c_puct, seats, terminal, children, qr,
+           exp_table, B, T, A, S, 0};
+    const int G = pick_group(B, A), K = pick_k(A, G);
+    const int lds_terms = (8 * A + 15) & ~15;
+    const int per = lds_terms + ((2 * A + 15) & ~15);
+    const int blocks = (B + 64 / G - 1) / (64 / G);
+#define CALL(g, k) hipLaunchKernelGGL((root_kernel<g, k>), dim3(blocks), dim3(64), (size_t)per * (64 / g), \
+                                      (hipStream_t)stream, m, (uint16_t*)probs, lds_terms)
+    BL_DISPATCH_GK(G, K, CALL)
+#undef CALL
+    return check_launch();
+}
+
+int bl_mcts_backup(const void* v, void* w, int16_t* n, const void* rewards, const int16_t* parents, const uint8_t* terminal,
+                   const int16_t* leaves, int B, int T, int S, bl_stream_t stream) {
+    if (!v || !w || !n || !rewards || !parents || !terminal || !leaves || B <= 0 || T <= 0 || S <= 0) return BL_EINVAL;
+    if (T > 32767 || S > 8) return BL_ETOOBIG;
+    const long threads = (long)B * S;
+    hipLaunchKernelGGL(backup_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const uint16_t*)v, (uint16_t*)w, n, (const uint16_t*)rewards, parents, terminal, leaves, B, T, S);
+    return check_launch();
+}
+
+int bl_hex_step(uint8_t* board, const int32_t* seats, const int32_t* actions, float* rewards, int B, int S, bl_stream_t stream) {
+    if (!board || !seats || !actions || !rewards || B <= 0 || S <= 0) return BL_EINVAL;
+    if (S > 32) return BL_ETOOBIG;
+    constexpr int G = 16;
+    const int blocks = (B + 64 / G - 1) / (64 / G);
+    hipLaunchKernelGGL((hex_step_kernel<G>), dim3(blocks), dim3(64), (size_t)((S * S + 15) & ~15) * (64 / G),
+                       (hipStream_t)stream, board, seats, actions, rewards, B, S);
+    return check_launch();
+}
+
+int bl_hex_observe(const uint8_t* board, const int32_t* seats, float* obs, int B, int S, bl_stream_t stream) {
+    if (!board || !seats || !obs || B <= 0 || S <= 0) return BL_EINVAL;
+    if (S > 32) return BL_ETOOBIG;
+    const long cells = (long)B * S * S;
+    long blocks = (cells + 255) / 256; if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(hex_observe_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, board, seats,
+                       (float2*)obs, cells, S);
+    return check_launch();
+}
+
+static int search_check(const bl_search_t* s) {
+    if (!s || !s->logits || !s->v || !s->w || !s->n || !s->children || !s->parents || !s->relation || !s->rewards ||
+        !s->terminal || !s->boards || !s->seats || !s->c_puct || !s->qrange || !s->exp_table) return BL_EINVAL;
+    if (s->B <= 0 || s->T <= 0 || s->boardsize <= 0) return BL_EINVAL;
+    if (s->boardsize > 32 || s->T > 32767) return BL_ETOOBIG;
+    return BL_OK;
+}
+
+static Search to_search(const bl_search_t* s) {
+    return Search{(uint16_t*)s->logits, (uint16_t*)s->v, (uint16_t*)s->w, s->n, s->children, s->parents, s->relation,
+                  (uint16_t*)s->rewards, s->terminal, s->boards, s->seats, (const uint16_t*)s->c_puct, s->qrange,
+                  s->exp_table, s->B, s->T, s->boardsize};
+}
+
+static int sim_expand_impl(const bl_search_t* s, int sim, const void* rands, int16_t* leaves, float* obs, uint8_t* valid,
+                           int32_t* leaf_seats, unsigned long long* counters, bl_stream_t stream) {
+    int rc = search_check(s);
+    if (rc) return rc;
+    if (!rands || !leaves || !obs || !valid || !leaf_seats || sim < 1 || sim >= s->T) return BL_EINVAL;
+    const int A = s->boardsize * s->boardsize;
+    const int G = pick_group(s->B, A), K = pick_k(A, G);
+    const int lds_terms = (8 * A + 15) & ~15;
+    const int per = lds_terms + ((2 * A + 15) & ~15) + ((A + 15) & ~15);
+    const int blocks = (s->B + 64 / G - 1) / (64 / G);
+    Search ss = to_search(s);
+    if (counters) {
+#define CALL(g, k) hipLaunchKernelGGL((sim_expand_kernel<g, k, true>), dim3(blocks), dim3(64), (size_t)per * (64 / g), \
+                                      (hipStream_t)stream, ss, sim, (const uint16_t*)rands, leaves, (float2*)obs, valid, leaf_seats, lds_terms, counters)
+        BL_DISPATCH_GK(G, K, CALL)
+#undef CALL
+    } else {
+#define CALL(g, k) hipLaunchKernelGGL((sim_expand_kernel<g, k, false>), dim3(blocks), dim3(64), (size_t)per * (64 / g), \
+                                      (hipStream_t)stream, ss, sim, (const uint16_t*)rands, leaves, (float2*)obs, valid, leaf_seats, lds_terms, nullptr)
+        BL_DISPATCH_GK(G, K, CALL)
+#undef CALL
+    }
+    return check_launch();
+}
+
+int bl_sim_expand(const bl_search_t* s, int sim, const void* rands, int16_t* leaves, float* obs, uint8_t* valid,
+                  int32_t* leaf_seats, bl_stream_t stream) {
+    return sim_expand_impl(s, sim, rands, leaves, obs, valid, leaf_seats, nullptr, stream);
+}
+
+int bl_sim_expand_counted(const bl_search_t* s, int sim, const void* rands, int16_t* leaves, float* obs, uint8_t* valid,
+                          int32_t* leaf_seats, unsigned long long* counters, bl_stream_t stream) {
+    if (!counters) return BL_EINVAL;
+    return sim_expand_impl(s, sim, rands, leaves, obs, valid, leaf_seats, counters, stream);
+}
+
+int bl_sim_backup(const bl_search_t* s, int sim, const int16_t* leaves, const void* leaf_logits, int logits_dtype,
+                  const void* leaf_v, int v_dtype, bl_stream_t stream) {
+    int rc = search_check(s);
+    if (rc) return rc;
+    if (!leaves || !leaf_logits || !leaf_v || sim < 1 || sim >= s->T) return BL_EINVAL;
+    const int blocks = (s->B + 3) / 4;
+    hipLaunchKernelGGL(sim_backup_kernel, dim3(blocks), dim3(64), 0, (hipStream_t)stream, to_search(s), sim, leaves,
+                       leaf_logits, logits_dtype, leaf_v, v_dtype);
+    return check_launch();
+}
+
+int bl_sim_root(const bl_search_t* s, int sim, void* probs, bl_stream_t stream) {
+    int rc = search_check(s);
+    if (rc) return rc;
+    if (!probs || sim < 1 || sim > s->T) return BL_EINVAL;
+    const int A = s->boardsize * s->boardsize;
+    Tree m{(const uint16_t*)s->logits, (const uint16_t*)s->w, s->n, (const uint16_t*)s->c_puct, s->seats, s->terminal,
+           s->children, s->qrange + 2 * BL_QSLOTS * sim, s->exp_table, s->B, s->T, A, 2, 1};
+    const int G = pick_group(s->B, A), K = pick_k(A, G);
+    const int lds_terms = (8 * A + 15) & ~15;
+    const int per = lds_terms + ((2 * A + 15) & ~15);
+    const int blocks = (s->B + 64 / G - 1) / (64 / G);
+#define CALL(g, k) hipLaunchKernelGGL((root_kernel<g, k>), dim3(blocks), dim3(64), (size_t)per * (64 / g), \
+                                      (hipStream_t)stream, m, (uint16_t*)probs, lds_terms)
+    BL_DISPATCH_GK(G, K, CALL)
+#undef CALL
+    return check_launch();
+}
+
+int bl_sim_init(const bl_search_t* s, const uint8_t* root_board, const int32_t* root_seats, bl_stream_t stream) {
+    int rc = search_check(s);
+    if (rc) return rc;
+    if (!root_board || !root_seats) return BL_EINVAL;
+    hipStream_t hs = (hipStream_t)stream;
+    const size_t B = s->B, T = s->T, A = (size_t)s->boardsize * s->boardsize;
+    bool ok = true;
+    ok &= hipMemsetAsync(s->children, 0xff, B * T * A * 2, hs) == hipSuccess;
+    ok &= hipMemsetAsync(s->parents, 0xff, B * T * 2, hs) == hipSuccess;
+    ok &= hipMemsetAsync(s->relation, 0xff, B * T * 2, hs) == hipSuccess;
+    ok &= hipMemsetD16Async((hipDeviceptr_t)s->logits, 0x7e00, B * T * A, hs) == hipSuccess;   // f16 NaN, mcts/__init__.py:56
+    ok &= hipMemsetD16Async((hipDeviceptr_t)s->v, 0x7e00, B * T * 2, hs) == hipSuccess;
+    ok &= hipMemsetAsync(s->w, 0, B * T * 2 * 2, hs) == hipSuccess;
+    ok &= hipMemsetAsync(s->n, 0, B * T * 2, hs) == hipSuccess;
+    ok &= hipMemsetAsync(s->rewards, 0, B * T * 2 * 2, hs) == hipSuccess;
+    ok &= hipMemsetAsync(s->terminal, 0, B * T, hs) == hipSuccess;
+    ok &= hipMemsetAsync(s->qrange, 0, (T + 1) * 2 * BL_QSLOTS * sizeof(uint32_t), hs) == hipSuccess;
+    if (!ok) return BL_ELAUNCH;
+    long blocks = (long)((B * T * A + 255) / 256); if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(sim_replicate_kernel, dim3((unsigned)blocks), dim3(256), 0, hs, to_search(s), root_board, root_seats);
+    return check_launch();
+}
+
+}  // extern "C"

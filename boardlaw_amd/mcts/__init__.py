@@ -1,0 +1,280 @@
+"""Vectorised MCTS over thousands of parallel games: `MCTS`, `mcts()`, `MCTSAgent`, `DummyAgent`.
+
+Same surface, array names, layouts and random-draw order as boardlaw/mcts/__init__.py:13-257; the tree is a set of
+contiguous SoA tensors over (B envs, T node slots):
+
+    tree.children (B,T,A) i16 = -1     tree.parents, tree.relation (B,T) i16 = -1
+    decisions.logits (B,T,A) f16 = NaN decisions.v (B,T,S) f16 = NaN
+    stats.n (B,T) i16 = 0              stats.w (B,T,S) f16 = 0
+    transitions.rewards (B,T,S) f16    transitions.terminal (B,T) bool
+    worlds: the env's own arrays stacked to (B,T,...)
+
+Two execution paths produce identical arrays:
+  * generic  -- any world type (the toy envs of validation.py, or Hex with fused=False): the reference's own sequence
+    of native calls (`cuda.descend`, `cuda.backup`, `cuda.root`) with torch indexing for the expansion glue;
+  * fused    -- Hex worlds: one simulation is `bl_sim_expand` -> network -> `bl_sim_backup` on the arrays above, no
+    host sync, `sim` kept on the host, capturable in a HIP graph.
+"""
+import ctypes
+
+import numpy as np
+import torch
+import torch.distributions
+
+from .. import _native, arrdict
+from . import cuda
+
+
+class TorchRng:
+    """The reference's three random draws, in its shapes/dtypes/order, from torch's default generator."""
+
+    def dirichlet(self, alpha, shape):
+        return torch.distributions.Dirichlet(alpha).sample(shape)          # mcts/__init__.py:16-18
+
+    def rand_like(self, x):
+        return torch.rand_like(x)                                           # mcts/cpp/cuda.cu:191
+
+    def categorical(self, logits):
+        return torch.distributions.Categorical(logits=logits).sample()      # mcts/__init__.py:221
+
+
+def dirichlet_noise(logits, valid, eps, alpha_scale=10, rng=None):
+    """mcts/__init__.py:13-24: mix a Dirichlet(alpha_scale/A) draw over the valid actions into the root prior."""
+    rng = rng or TorchRng()
+    alpha = torch.full((valid.shape[-1],), alpha_scale / logits.size(-1), dtype=torch.float, device=logits.device)
+    draw = rng.dirichlet(alpha, logits.shape[:-1])
+    draw[~valid] = 0.
+    draw = draw / draw.sum(-1, keepdims=True)
+    return (logits.exp() * (1 - eps) + draw * eps).log()
+
+
+class LeafWorlds:
+    """What the network sees of the freshly expanded leaves on the fused path: obs/valid/seats were written by
+    bl_sim_expand; the boards stay in the tree and are gathered only if someone asks."""
+
+    def __init__(self, search, leaves, obs, valid, seats):
+        self._search, self._leaves = search, leaves
+        self.obs, self.valid, self.seats = obs, valid, seats
+        self.n_envs, self.n_seats, self.device = obs.shape[0], 2, obs.device
+
+    @property
+    def board(self):
+        return self._search.worlds.board[self._search.envs, self._leaves.long()]
+
+
+class MCTS:
+
+    def __init__(self, world, n_nodes=64, c_puct=1 / 16, noise_eps=.25, alpha_scale=10, fused=None, rng=None,
+                 count=False):
+        """c_puct high: concentrates on prior; c_puct low: concentrates on value (mcts/__init__.py:29-33)."""
+        from .. import hex as hexmod
+        self.device = world.device
+        self.n_envs = world.n_envs
+        self.n_nodes = n_nodes
+        self.n_seats = world.n_seats
+        assert n_nodes > 0, 'MCTS requires at least one node'
+        self.n_actions = int(np.prod(world.action_space))
+        self.noise_eps, self.alpha_scale = noise_eps, alpha_scale
+        self.rng = rng or TorchRng()
+        self.fused = isinstance(world, hexmod.Hex) if fused is None else fused
+        if self.fused and not isinstance(world, hexmod.Hex):
+            raise ValueError('The fused path is Hex-only')
+        B, T, A, S, dev = self.n_envs, n_nodes, self.n_actions, self.n_seats, self.device
+        self.envs = torch.arange(B, device=dev)
+        self.sim = 0
+        self.c_puct = torch.full((B,), c_puct, device=dev, dtype=torch.half)
+        self._root_world = world
+
+        if self.fused:
+            _native.require_device(world.board)
+            e = lambda *shape, dtype: torch.empty(shape, device=dev, dtype=dtype)
+            bs = world.boardsize
+            self.tree = arrdict.arrdict(children=e(B, T, A, dtype=torch.short), parents=e(B, T, dtype=torch.short),
+                                        relation=e(B, T, dtype=torch.short))
+            self.worlds = type(world)(board=e(B, T, bs, bs, dtype=torch.uint8), seats=e(B, T, dtype=torch.int))
+            self.transitions = arrdict.arrdict(rewards=e(B, T, S, dtype=torch.half), terminal=e(B, T, dtype=torch.bool))
+            self.decisions = arrdict.arrdict(logits=e(B, T, A, dtype=torch.half), v=e(B, T, S, dtype=torch.half))
+            self.stats = arrdict.arrdict(n=e(B, T, dtype=torch.short), w=e(B, T, S, dtype=torch.half))
+            self._qrange = e(T + 1, _native.QRANGE_WORDS, dtype=torch.int32)
+            self._exp = _native.exp_table(dev)
+            self._leaves = e(B, dtype=torch.short)
+            self._obs = e(B, bs, bs, 2, dtype=torch.float)
+            self._valid = e(B, A, dtype=torch.bool)
+            self._leaf_seats = e(B, dtype=torch.int)
+            self.counters = torch.zeros(3, dtype=torch.int64, device=dev) if count else None
+            self._search = _native.Search(
+                logits=self.decisions.logits.data_ptr(), v=self.decisions.v.data_ptr(), w=self.stats.w.data_ptr(),
+                n=self.stats.n.data_ptr(), children=self.tree.children.data_ptr(), parents=self.tree.parents.data_ptr(),
+                relation=self.tree.relation.data_ptr(), rewards=self.transitions.rewards.data_ptr(),
+                terminal=self.transitions.terminal.data_ptr(), boards=self.worlds.board.data_ptr(),
+                seats=self.worlds.seats.data_ptr(), c_puct=self.c_puct.data_ptr(), qrange=self._qrange.data_ptr(),
+                exp_table=self._exp.data_ptr(), B=B, T=T, boardsize=bs)
+            with torch.cuda.device(dev):
+                _native.check(_native.lib().bl_sim_init(ctypes.byref(self._search), world.board.contiguous().data_ptr(),
+                                                        world.seats.int().contiguous().data_ptr(), _native.stream(dev)))
+        else:
+            f = lambda shape, value, dtype: torch.full(shape, value, device=dev, dtype=dtype)
+            self.tree = arrdict.arrdict(children=f((B, T, A), -1, torch.short), parents=f((B, T), -1, torch.short),
+                                        relation=f((B, T), -1, torch.short))
+            self.worlds = arrdict.stack([world for _ in range(T)], 1)
+            self.transitions = arrdict.arrdict(rewards=f((B, T, S), 0., torch.half), terminal=f((B, T), False, torch.bool))
+            self.decisions = arrdict.arrdict(logits=f((B, T, A), np.nan, torch.half), v=f((B, T, S), np.nan, torch.half))
+            self.stats = arrdict.arrdict(n=f((B, T), 0, torch.short), w=f((B, T, S), 0., torch.half))
+            self.worlds[:, 0] = world
+
+    # ------------------------------------------------------------------ mcts/__init__.py:72-80
+    def initialize(self, network):
+        world = self._root_world if self.fused else self.worlds[:, 0]
+        with torch.no_grad():
+            decisions = network(world)
+        self.plant_root(dirichlet_noise(decisions.logits, world.valid, self.noise_eps, self.alpha_scale, self.rng), decisions.v)
+
+    def plant_root(self, logits, v):
+        """Stores the root evaluation (what initialize does after the network call); also the entry point for replaying
+        a recorded search."""
+        assert self.sim == 0
+        self.decisions.logits[:, 0] = logits
+        self.decisions.v[:, 0] = v
+        self.sim = 1
+
+    # ------------------------------------------------------------------ generic path, mcts/__init__.py:82-140
+    def _cuda(self):
+        return cuda.mcts(self.decisions.logits, self.stats.w, self.stats.n, self.c_puct, self.worlds.seats,
+                         self.transitions.terminal, self.tree.children)
+
+    def descend(self):
+        m = self._cuda()
+        result = cuda.descend(m, self.rng.rand_like(m.logits[:, :, 0]))
+        return result.parents.long(), result.actions.long()
+
+    def backup(self, leaves):
+        bk = cuda.Backup(v=self.decisions.v, w=self.stats.w, n=self.stats.n, rewards=self.transitions.rewards,
+                         parents=self.tree.parents, terminal=self.transitions.terminal)
+        cuda.backup(bk, leaves.short())
+
+    def _simulate_generic(self, network):
+        parents, actions = self.descend()
+        # a descent that stopped on a terminal node re-visits it instead of creating a node
+        leaves = self.tree.children[self.envs, parents, actions].long()
+        leaves[leaves == -1] = self.sim
+        self.tree.children[self.envs, parents, actions] = leaves.short()
+        self.tree.parents[self.envs, leaves] = parents.short()
+        self.tree.relation[self.envs, leaves] = actions.short()
+
+        world, transition = self.worlds[self.envs, parents].step(actions)
+        self.worlds[self.envs, leaves] = world
+        self.transitions.rewards[self.envs, leaves] = transition.rewards.half()
+        self.transitions.terminal[self.envs, leaves] = transition.terminal
+
+        with torch.no_grad(), torch.autocast('cuda', enabled=(self.device.type == 'cuda')):
+            decisions = network(world)
+        self.decisions.logits[self.envs, leaves] = decisions.logits.half()
+        self.decisions.v[self.envs, leaves] = decisions.v.half()
+        self.backup(leaves)
+
+    # ------------------------------------------------------------------ fused path
+    def _simulate_fused(self, network):
+        L, s, dev = _native.lib(), ctypes.byref(self._search), self.device
+        rands = self.rng.rand_like(self.decisions.logits[:, :, 0])
+        assert rands.is_contiguous() and rands.dtype == torch.half
+        with torch.cuda.device(dev):
+            st = _native.stream(dev)
+            if self.counters is None:
+                _native.check(L.bl_sim_expand(s, self.sim, rands.data_ptr(), self._leaves.data_ptr(), self._obs.data_ptr(),
+                                              self._valid.data_ptr(), self._leaf_seats.data_ptr(), st))
+            else:
+                _native.check(L.bl_sim_expand_counted(s, self.sim, rands.data_ptr(), self._leaves.data_ptr(),
+                                                      self._obs.data_ptr(), self._valid.data_ptr(),
+                                                      self._leaf_seats.data_ptr(), self.counters.data_ptr(), st))
+            world = LeafWorlds(self, self._leaves, self._obs, self._valid, self._leaf_seats)
+            with torch.no_grad(), torch.autocast('cuda', enabled=True):
+                decisions = network(world)
+            logits, v = decisions.logits.contiguous(), decisions.v.contiguous()
+            kinds = {torch.float: 0, torch.half: 1}
+            if logits.dtype not in kinds or v.dtype not in kinds:
+                logits, v = logits.float(), v.float()
+            assert logits.shape == (self.n_envs, self.n_actions) and v.shape == (self.n_envs, 2)
+            _native.check(L.bl_sim_backup(s, self.sim, self._leaves.data_ptr(), logits.data_ptr(), kinds[logits.dtype],
+                                          v.data_ptr(), kinds[v.dtype], st))
+
+    def simulate(self, network):
+        if self.sim >= self.n_nodes:
+            raise ValueError('Called simulate more times than were declared in the constructor')
+        if self.fused:
+            self._simulate_fused(network)
+        else:
+            self._simulate_generic(network)
+        self.sim += 1
+
+    # ------------------------------------------------------------------ mcts/__init__.py:142-152
+    def root_probs(self):
+        if self.fused:
+            probs = torch.empty((self.n_envs, self.n_actions), dtype=torch.half, device=self.device)
+            with torch.cuda.device(self.device):
+                _native.check(_native.lib().bl_sim_root(ctypes.byref(self._search), self.sim, probs.data_ptr(),
+                                                        _native.stream(self.device)))
+            return probs
+        return cuda.root(self._cuda())
+
+    def root(self):
+        r = self.root_probs()
+        return arrdict.arrdict(
+            logits=r.log() if r.device.type == 'cuda' else r.float().log().half(),
+            prior=self.decisions.logits[:, 0],
+            v=self.decisions.v[:, 0])
+
+    def n_leaves(self):
+        return ((self.tree.children == -1).all(-1) & (self.tree.parents != -1)).sum(-1)
+
+
+def mcts(worlds, network, **kwargs):
+    m = MCTS(worlds, **kwargs)
+    m.initialize(network)
+    for _ in range(m.n_nodes - 1):
+        m.simulate(network)
+    return m
+
+
+class MCTSAgent:
+    """mcts/__init__.py:209-241.  Output arrdict: logits (B,A) f16, prior (B,A) f16, n_sims (B) i64, n_leaves (B) i64,
+    v (B,S) f16, actions (B) i64."""
+
+    def __init__(self, network, **kwargs):
+        self.network = network
+        self.kwargs = kwargs
+
+    def __call__(self, world, value=True, eval=False, **kwargs):
+        m = mcts(world, self.network, **{**self.kwargs, **kwargs})
+        r = m.root()
+        actions = r.logits.argmax(-1) if eval else m.rng.categorical(r.logits.float())
+        return arrdict.arrdict(
+            logits=r.logits,
+            prior=r.prior,
+            n_sims=torch.full_like(m.envs, m.sim + 1),     # the reference's off-by-one, kept
+            n_leaves=m.n_leaves(),
+            v=r.v,
+            actions=actions).clone()
+
+    def load_state_dict(self, sd):
+        self.network.load_state_dict({k[len('network.'):]: v for k, v in sd.items() if k.startswith('network.')})
+        self.kwargs.update({k[len('kwargs.'):]: v for k, v in sd.items() if k.startswith('kwargs.')})
+
+    def state_dict(self):
+        return {**{f'network.{k}': v for k, v in self.network.state_dict().items()},
+                **{f'kwargs.{k}': v for k, v in self.kwargs.items()}}
+
+
+class DummyAgent:
+    """Acts straight from the network, no search (mcts/__init__.py:243-257)."""
+
+    def __init__(self, network):
+        self.network = network
+
+    def __call__(self, world, eval=False):
+        r = self.network(world)
+        actions = r.logits.argmax(-1) if eval else torch.distributions.Categorical(logits=r.logits.float()).sample()
+        return arrdict.arrdict(
+            logits=r.logits, prior=r.logits,
+            n_sims=torch.full((world.n_envs,), 0, device=world.device),
+            n_leaves=torch.full((world.n_envs,), 1, device=world.device),
+            v=r.v, actions=actions).clone()

@@ -1,0 +1,144 @@
+/* boardlaw_amd.h -- C ABI of libboardlaw_amd.so: the MI355X (gfx950) drop-in for boardlaw's two native modules.
+ *
+ * The reference has no C ABI: its boundary is two pybind11/ATen modules (`mctscuda`, `hexcuda`) JIT-built by
+ * boardlaw/cuda.py:48-63 and wrapped by boardlaw/mcts/cuda.py and boardlaw/hex/cuda.py.  Each entry point below
+ * names the reference binding it replaces; INTEGRATION.md shows the ctypes stub a boardlaw maintainer would put in
+ * boardlaw/mcts/cuda.py / boardlaw/hex/cuda.py to call it.
+ *
+ * Conventions (all functions):
+ *   - plain pointers and sizes, no torch types; every pointer is a DEVICE pointer unless its name says host_;
+ *   - all buffers (inputs, outputs, scratch) are owned by the caller, contiguous row-major, dtypes as listed:
+ *       f16  = IEEE binary16 (torch.half)   i16 = int16_t (torch.short)   u8 = uint8_t (torch.bool / torch.uint8)
+ *   - work is enqueued on `stream` (a hipStream_t passed as void*) and NOT synchronised, like the reference's
+ *     launches on the current torch stream (boardlaw/cpp/kernels.cu:8-10); safe inside hipGraph capture
+ *     (no allocation, no synchronisation, no host-side state);
+ *   - return 0 on success, a negative BL_E* code otherwise (never throws); bl_strerror() describes it;
+ *   - re-entrant and GIL-free: the library keeps no global mutable state.
+ *
+ * Shapes: B envs, T node slots per env, A actions (= board cells), S seats.
+ */
+#ifndef BOARDLAW_AMD_H
+#define BOARDLAW_AMD_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BL_OK 0
+#define BL_EINVAL (-1)     /* bad size / null pointer */
+#define BL_ETOOBIG (-2)    /* A, T or S beyond what the kernels support (A <= 1024, T <= 32767, S <= 8, board <= 32) */
+#define BL_ELAUNCH (-3)    /* hipGetLastError() != hipSuccess after the launch (reference: C10_CUDA_CHECK) */
+
+#define BL_QRANGE_WORDS 128 /* u32 words in one q-range state: 64 slots x {~enc(min), enc(max)} */
+
+typedef void* bl_stream_t; /* hipStream_t */
+
+int bl_abi_version(void);
+const char* bl_strerror(int code);
+
+/* pi = expf(logit) for every binary16 bit pattern, computed by the host libm -- the function the reference's CPU
+ * path calls at boardlaw/mcts/cpp/cpu.cpp:86,90.  The caller uploads the 65536 floats once per device and passes the
+ * device copy as `exp_table` below; this keeps the GPU's pi bit-identical to the reference CPU path's. */
+int bl_exp_table_host(float* host_table /* 65536 floats, HOST memory */);
+
+/* ---- transition_q's batch-global range (boardlaw/mcts/cpp/cuda.cu:101-105) --------------------------------------
+ * qrange_state: BL_QRANGE_WORDS x u32, device: 64 slots of {max of ~enc(q), max of enc(q)} over the slot's share of
+ * the B*T*S values q = f32(w)/(f32(n)+1e-4f); enc = the order-preserving float->u32 map.  Spreading the atomics
+ * over 64 addresses keeps the reduction off a single L2 atomic unit; consumers max-reduce the 64 slots in one wave
+ * load.  bl_mcts_qrange zeroes the state itself (memset node) and reduces into it; shards that want the reference's
+ * *global* normalisation all-reduce(MAX) the words across ranks.  bl_qrange_decode turns a HOST copy into {min,max}. */
+int bl_mcts_qrange(const void* w /*f16 (B,T,S)*/, const int16_t* n /*(B,T)*/, int B, int T, int S,
+                   uint32_t* qrange_state, bl_stream_t stream);
+int bl_qrange_decode(const uint32_t host_state[BL_QRANGE_WORDS], float host_minmax[2]);
+
+/* ---- mctscuda.descend(m) -> Descent{parents, actions}   (boardlaw/mcts/cpp/wrappers.cpp:24-30, cuda.cu:138-203) --
+ * `rands` is the (B,T) f16 tensor the reference draws internally with at::rand_like (cuda.cu:191); the host wrapper
+ * draws it with torch so the generator is consumed identically.  seats are i16 (B,T) as in the reference's MCTS
+ * struct (mcts/cpp/common.h:25-33). */
+int bl_mcts_descend(const void* logits /*f16 (B,T,A)*/, const void* w /*f16 (B,T,S)*/, const int16_t* n /*(B,T)*/,
+                    const void* c_puct /*f16 (B)*/, const int16_t* seats /*(B,T)*/, const uint8_t* terminal /*(B,T)*/,
+                    const int16_t* children /*(B,T,A)*/, const void* rands /*f16 (B,T)*/,
+                    const uint32_t* qrange_state, const float* exp_table,
+                    int B, int T, int A, int S,
+                    int16_t* parents_out /*(B)*/, int16_t* actions_out /*(B)*/, bl_stream_t stream);
+
+/* ---- mctscuda.root(m) -> (B,A) f16 probabilities   (wrappers.cpp:32-38, cuda.cu:107-136) ------------------------- */
+int bl_mcts_root(const void* logits, const void* w, const int16_t* n, const void* c_puct, const int16_t* seats,
+                 const uint8_t* terminal, const int16_t* children,
+                 const uint32_t* qrange_state, const float* exp_table,
+                 int B, int T, int A, int S, void* probs_out /*f16 (B,A)*/, bl_stream_t stream);
+
+/* ---- mctscuda.backup(bk, leaves)   (wrappers.cpp:40-46, cuda.cu:205-248): mutates w and n in place -------------- */
+int bl_mcts_backup(const void* v /*f16 (B,T,S)*/, void* w /*f16 (B,T,S)*/, int16_t* n /*(B,T)*/,
+                   const void* rewards /*f16 (B,T,S)*/, const int16_t* parents /*(B,T)*/,
+                   const uint8_t* terminal /*(B,T)*/, const int16_t* leaves /*(B)*/,
+                   int B, int T, int S, bl_stream_t stream);
+
+/* ---- hexcuda.step(board, seats, actions) -> (B,2) f32   (hex/cpp/wrappers.cpp:20-26, cuda.cu:76-152) -------------
+ * board (B,S,S) u8 is mutated in place (the caller clones, hex/__init__.py:181); rewards_out is fully written
+ * (zeros unless the move wins).  No legality check, like the reference. */
+int bl_hex_step(uint8_t* board, const int32_t* seats, const int32_t* actions, float* rewards_out /*(B,2)*/,
+                int B, int boardsize, bl_stream_t stream);
+
+/* ---- hexcuda.observe(board, seats) -> (B,S,S,2) f32   (hex/cpp/wrappers.cpp:28-34, cuda.cu:154-217) -------------
+ * Leading dims are flattened by the caller.  obs_out is fully written. */
+int bl_hex_observe(const uint8_t* board, const int32_t* seats, float* obs_out, int B, int boardsize, bl_stream_t stream);
+
+/* ================= fused search step for Hex (no reference counterpart) ==================
+ * One simulation of boardlaw/mcts/__init__.py:108-140 is  descend -> expand -> world.step -> observe -> network ->
+ * store -> backup.  The reference runs ~25 torch ops and 4 host syncs around its three kernels; here everything
+ * before the network is bl_sim_expand and everything after it is bl_sim_backup, operating directly on the search's
+ * SoA arrays (same names/layouts as MCTS.tree/stats/decisions/transitions/worlds). */
+typedef struct {
+    /* MCTS.decisions / stats / tree / transitions / worlds, all (B,T,...) */
+    void* logits;        /* f16 (B,T,A) */
+    void* v;             /* f16 (B,T,2) */
+    void* w;             /* f16 (B,T,2) */
+    int16_t* n;          /* (B,T) */
+    int16_t* children;   /* (B,T,A) */
+    int16_t* parents;    /* (B,T) */
+    int16_t* relation;   /* (B,T) */
+    void* rewards;       /* f16 (B,T,2) */
+    uint8_t* terminal;   /* (B,T) */
+    uint8_t* boards;     /* (B,T,S,S) */
+    int32_t* seats;      /* (B,T) */
+    const void* c_puct;  /* f16 (B) */
+    uint32_t* qrange;    /* (T+1, BL_QRANGE_WORDS) u32: row s is the state descend #s reads; bl_sim_init resets it */
+    const float* exp_table;
+    int B, T, boardsize;
+} bl_search_t;
+
+/* mcts/__init__.py:113-129 + hex/__init__.py:148-195 for simulation number `sim` (1..T-1):
+ * reads qrange slot `sim`, descends, creates/looks up the leaf, steps the parent's board, stores the leaf world and
+ * its transition, and emits what the network needs for the leaf worlds. */
+int bl_sim_expand(const bl_search_t* s, int sim, const void* rands /*f16 (B,T)*/,
+                  int16_t* leaves_out /*(B)*/, float* obs_out /*(B,S,S,2) f32*/, uint8_t* valid_out /*(B,A)*/,
+                  int32_t* leaf_seats_out /*(B)*/, bl_stream_t stream);
+
+/* mcts/__init__.py:135-140: stores the network's outputs for the leaves (rounding to f16 exactly like `.half()`),
+ * runs the backup walk, and reduces the q-range for descend #(sim+1) into qrange slot sim+1.
+ * logits_dtype / v_dtype: 0 = f32, 1 = f16. */
+int bl_sim_backup(const bl_search_t* s, int sim, const int16_t* leaves /*(B)*/,
+                  const void* leaf_logits /*(B,A)*/, int logits_dtype, const void* leaf_v /*(B,2)*/, int v_dtype,
+                  bl_stream_t stream);
+
+/* root distribution from qrange slot `sim` (call with sim = number of filled slots, i.e. MCTS.sim). */
+int bl_sim_root(const bl_search_t* s, int sim, void* probs_out /*f16 (B,A)*/, bl_stream_t stream);
+
+/* MCTS.__init__ (mcts/__init__.py:43-67): children/parents/relation = -1, logits/v = NaN, w/n/rewards/terminal = 0,
+ * every slot's board/seat = the root world's, qrange slots zeroed. */
+int bl_sim_init(const bl_search_t* s, const uint8_t* root_board /*(B,S,S)*/, const int32_t* root_seats /*(B)*/,
+                bl_stream_t stream);
+
+/* Diagnostics for the roofline model: per-launch totals accumulated by bl_sim_expand when `counters`
+ * (3 x u64, device, caller-zeroed) is set with bl_sim_expand_counted: [0] policy evaluations (d), [1] expanded-child
+ * lookups (k), [2] Newton iterations. */
+int bl_sim_expand_counted(const bl_search_t* s, int sim, const void* rands, int16_t* leaves_out, float* obs_out,
+                          uint8_t* valid_out, int32_t* leaf_seats_out, unsigned long long* counters,
+                          bl_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,328 @@
+"""GPU parity: the HIP path (through the C ABI of libboardlaw_amd.so) against the CPU oracle and the reference's
+golden vectors.  Bit-exact: every integer, byte, index and binary16 output must be identical (tolerance = 0).
+Run on an MI355X with `pytest -m gpu`."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from gpu_util import HashNetwork, ReplayNetwork, ReplayRng, bits16, hash_network_np, t16, to_np
+from oracle_lib import OracleSearch, f16_bits
+from test_oracle import OPS, SEARCHES, gold, op_cases, random_tree, bits
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+
+
+@pytest.fixture(scope='module', autouse=True)
+def _native_loaded():
+    assert torch.cuda.is_available(), 'these tests need the MI355X'
+    from boardlaw_amd import _native
+    _native.lib()          # raises if the HIP extension is missing: there is no fallback to test
+
+
+def dev(x):
+    """numpy fixture array -> device tensor with the dtype the C ABI expects."""
+    if x.dtype == np.uint16:
+        return t16(x, DEV)
+    t = torch.from_numpy(np.ascontiguousarray(x)).to(DEV)
+    return t
+
+
+def tree_tensors(g, c, tile=1):
+    d = {k: np.ascontiguousarray(g[f'{c}_{k}']) for k in ('logits', 'w', 'n', 'c_puct', 'seats', 'terminal', 'children')}
+    d = {k: np.concatenate([v] * tile, 0) for k, v in d.items()}
+    t = {k: dev(v) for k, v in d.items()}
+    t['terminal'] = t['terminal'].bool()
+    return t
+
+
+# ------------------------------------------------------------------------------------------------ Hex kernels
+@pytest.mark.parametrize('S', [3, 4, 5, 7, 9, 11, 13])
+def test_hex_step_observe_golden(S):
+    from boardlaw_amd.hex import cuda as hcuda, Hex
+    g = gold('hex_playouts.npz')
+    boards, seats, actions = g[f'S{S}_board'], g[f'S{S}_seats'], g[f'S{S}_actions']
+    n = boards.shape[0] * boards.shape[1]
+    fb = torch.from_numpy(boards.reshape(n, S, S)).to(DEV)
+    fs = torch.from_numpy(seats.reshape(n).astype(np.int32)).to(DEV)
+    fa = torch.from_numpy(actions.reshape(n).astype(np.int32)).to(DEV)
+    obs = hcuda.observe(fb, fs)
+    assert np.array_equal(to_np(obs).astype(np.uint8), g[f'S{S}_obs'].reshape(n, S, S, 2))
+    raw = fb.clone()
+    rewards = hcuda.step(raw, fs, fa)
+    assert np.array_equal(to_np(raw), g[f'S{S}_raw_board'].reshape(n, S, S))
+    assert np.array_equal(to_np(rewards), g[f'S{S}_rewards'].reshape(n, 2))
+    # the world object on top (hex/__init__.py:161-195)
+    world = Hex(board=fb, seats=fs)
+    assert np.array_equal(to_np(world.valid), g[f'S{S}_valid'].reshape(n, S * S))
+    new, trans = world.step(fa.long())
+    assert np.array_equal(to_np(new.board), g[f'S{S}_new_board'].reshape(n, S, S))
+    assert np.array_equal(to_np(new.seats), g[f'S{S}_new_seats'].reshape(n))
+    assert np.array_equal(to_np(trans.terminal), g[f'S{S}_terminal'].reshape(n))
+
+
+@pytest.mark.parametrize('S,B', [(2, 7), (9, 4096), (13, 4096), (19, 1000), (32, 64)])
+def test_hex_random_games_vs_oracle(oracle, S, B):
+    """Random legal play from empty boards to the end of several games, both seats, ragged batch sizes."""
+    from boardlaw_amd.hex import cuda as hcuda
+    rng = np.random.default_rng(S)
+    board = np.zeros((B, S, S), np.uint8); seats = np.zeros(B, np.int32)
+    for step in range(min(3 * S * S, 400)):
+        obs = oracle.hex_observe(board, seats)
+        valid = (obs == 0).all(-1).reshape(B, -1)
+        r = rng.random(valid.shape) * valid
+        actions = r.argmax(-1).astype(np.int32)
+        tb, ts, ta = torch.from_numpy(board).to(DEV), torch.from_numpy(seats).to(DEV), torch.from_numpy(actions).to(DEV)
+        assert np.array_equal(to_np(hcuda.observe(tb, ts)), obs), step
+        rewards = hcuda.step(tb, ts, ta)
+        raw = board.copy(); want = oracle.hex_step(raw, seats, actions)
+        assert np.array_equal(to_np(tb), raw), step
+        assert np.array_equal(to_np(rewards), want), step
+        board, seats, _, _ = oracle.hex_world_step(board, seats, actions)
+
+
+def test_hex_reference_known_answers():
+    """boardlaw/hex/tests.py:58-91 and hex/__init__.py:274-297 through the product's Hex world."""
+    from boardlaw_amd.hex import Hex, cuda as hcuda
+    def tok(*moves):
+        b = torch.zeros((1, 3, 3), dtype=torch.uint8, device=DEV)
+        for ij, v in moves:
+            b[0, ij // 3, ij % 3] = v
+        return b
+    def apply(seat, action, board):
+        return hcuda.step(board, torch.tensor([seat], dtype=torch.int32, device=DEV), torch.tensor([action], dtype=torch.int32, device=DEV))
+    b = tok(); r = apply(0, 2, b); assert torch.equal(b, tok((2, 3))) and (r == 0).all()          # black TR -> TOP
+    b = tok(); r = apply(1, 2, b); assert torch.equal(b, tok((6, 5)))                              # white TR mirrored -> BL LEFT
+    b = tok((3, 1), (4, 1)); apply(0, 7, b); assert torch.equal(b, tok((3, 4), (4, 4), (7, 4)))    # bottom flooding
+    b = tok((1, 2), (4, 2)); apply(1, 1, b); assert torch.equal(b, tok((1, 5), (4, 5), (3, 5)))    # left flooding
+    assert apply(0, 4, tok((1, 3), (7, 4))).tolist() == [[1., -1.]]
+    assert apply(1, 4, tok((3, 5), (5, 6))).tolist() == [[-1., 1.]]
+    w = Hex.initial(1, 3, device=DEV)
+    for a in [5, 5, 6, 1]:
+        w, _ = w.step(torch.tensor([a], device=DEV))
+    assert w.board[0].tolist() == [[0, 0, 0], [5, 0, 1], [4, 2, 0]]
+    w = Hex(board=torch.tensor([[[0, 6, 6], [1, 1, 1], [0, 2, 0]]], dtype=torch.uint8, device=DEV), seats=torch.zeros(1, dtype=torch.int, device=DEV))
+    w, _ = w.step(torch.tensor([6], device=DEV))
+    assert w.board[0].tolist() == [[0, 6, 6], [4, 4, 4], [4, 2, 0]]
+
+
+# ------------------------------------------------------------------------------------------------ search kernels
+@pytest.mark.parametrize('name', OPS)
+@pytest.mark.parametrize('tile', [1, 37, 70, 260])
+def test_descend_root_backup_golden(name, tile):
+    """Reference trees from live searches; tiling the batch moves the launch through every lanes-per-env group width
+    (64, 32, 16, 8) without changing the expected per-env answers (the q range is batch-global and tile-invariant)."""
+    from boardlaw_amd.mcts import cuda as mcuda
+    from boardlaw_amd import _native
+    g = gold(name)
+    if tile > 70 and g[op_cases(g, 'descend')[0] + '_logits'].shape[2] > 100:
+        pytest.skip('memory-heavy duplicate of the smaller boards')
+    for c in op_cases(g, 'descend'):
+        t = tree_tensors(g, c, tile)
+        m = mcuda.mcts(**t)
+        rands = dev(np.concatenate([g[f'{c}_rands']] * tile, 0))
+        d = mcuda.descend(m, rands)
+        assert np.array_equal(to_np(d.parents), np.tile(g[f'{c}_parents'], tile)), c
+        assert np.array_equal(to_np(d.actions), np.tile(g[f'{c}_actions'], tile)), c
+        assert np.array_equal(bits16(mcuda.root(m)), np.tile(g[f'{c}_root_probs'], (tile, 1))), c
+        mm = _native.qrange_decode(mcuda._qrange(m, torch.device(DEV, torch.cuda.current_device())))
+        assert np.array_equal(mm.numpy(), g[f'{c}_qminmax']), c
+    for c in op_cases(g, 'backup'):
+        t = {k: dev(np.concatenate([g[f'{c}_{k}']] * tile, 0)) for k in ('v', 'w', 'n', 'rewards', 'parents', 'terminal', 'leaves')}
+        t['terminal'] = t['terminal'].bool()
+        leaves = t.pop('leaves')
+        mcuda.backup(mcuda.Backup(**t), leaves)
+        assert np.array_equal(bits16(t['w']), np.concatenate([g[f'{c}_w_after']] * tile, 0)), c
+        assert np.array_equal(to_np(t['n']), np.concatenate([g[f'{c}_n_after']] * tile, 0)), c
+
+
+@pytest.mark.parametrize('B,T,A,filled', [(5, 6, 4, 5), (16, 12, 9, 12), (33, 40, 25, 33), (8, 64, 81, 64), (6, 64, 169, 50),
+                                          (3, 30, 361, 25), (2, 20, 1000, 12)])
+def test_random_trees_vs_oracle(oracle, B, T, A, filled):
+    """Structurally valid random trees incl. -inf logits, terminal nodes, ragged B, every supported lanes-per-action K."""
+    from boardlaw_amd.mcts import cuda as mcuda
+    rng = np.random.default_rng(A)
+    d = random_tree(rng, B, T, A, filled)
+    nd = {k: bits(v) for k, v in d.items()}
+    m = mcuda.mcts(**{k: v.to(DEV) for k, v in d.items()})
+    rands = torch.from_numpy(rng.random((B, T)).astype(np.float16).view(np.int16)).view(torch.half)
+    got = mcuda.descend(m, rands.to(DEV))
+    parents, actions = oracle.descend(**nd, rands=bits(rands))
+    assert np.array_equal(to_np(got.parents), parents) and np.array_equal(to_np(got.actions), actions)
+    assert np.array_equal(bits16(mcuda.root(m)), oracle.root(**nd))
+
+
+def test_struct_checks_match_reference():
+    """TensorProxy behaviour (boardlaw/cpp/common.h:33-37): dtype -> TypeError 'expected Half got Float', layout -> RuntimeError."""
+    from boardlaw_amd.mcts import cuda as mcuda
+    z = lambda *s, dtype: torch.zeros(s, dtype=dtype, device=DEV)
+    with pytest.raises(TypeError, match='expected Half got Float'):
+        mcuda.Backup(v=z(1, 2, 1, dtype=torch.float), w=z(1, 2, 1, dtype=torch.half), n=z(1, 2, dtype=torch.short),
+                     rewards=z(1, 2, 1, dtype=torch.half), parents=z(1, 2, dtype=torch.short), terminal=z(1, 2, dtype=torch.bool))
+    with pytest.raises(RuntimeError, match='contiguous'):
+        mcuda.MCTS(z(2, 3, 4, dtype=torch.half).transpose(0, 1), z(2, 3, 1, dtype=torch.half), z(2, 3, dtype=torch.short),
+                   z(2, dtype=torch.half), z(2, 3, dtype=torch.short), z(2, 3, dtype=torch.bool), z(2, 3, 4, dtype=torch.short))
+    with pytest.raises(AssertionError, match='c_puct'):
+        mcuda.mcts(z(2, 3, 4, dtype=torch.half), z(2, 3, 1, dtype=torch.half), z(2, 3, dtype=torch.short),
+                   z(2, dtype=torch.half), z(2, 3, dtype=torch.short), z(2, 3, dtype=torch.bool), z(2, 3, 4, dtype=torch.short))
+
+
+# ------------------------------------------------------------------------------------------------ whole searches
+def compare_search(m, g, p, move):
+    for mine, theirs in [(m.tree.children, 'children'), (m.tree.parents, 'parents'), (m.tree.relation, 'relation'),
+                         (m.stats.n, 'n'), (m.stats.w, 'w'), (m.transitions.rewards, 'rewards'),
+                         (m.transitions.terminal, 'terminal'), (m.worlds.board, 'boards'), (m.worlds.seats, 'seats'),
+                         (m.decisions.v, 'tree_v'), (m.decisions.logits, 'tree_logits')]:
+        assert np.array_equal(to_np(mine), g[p + theirs]), (move, theirs)
+    assert np.array_equal(bits16(m.root_probs()), g[p + 'root_probs']), move
+    assert np.array_equal(to_np(m.n_leaves()), g[p + 'dec_n_leaves']), move
+
+
+@pytest.mark.parametrize('name', SEARCHES)
+@pytest.mark.parametrize('fused', [True, False])
+def test_whole_search_replay(name, fused):
+    """Every recorded reference search (same uniforms, same network outputs) replayed through the product's MCTS on
+    the GPU, both execution paths: identical trees, visit counts, values, boards and root distributions."""
+    from boardlaw_amd.hex import Hex
+    from boardlaw_amd.mcts import MCTS
+    g = gold(name)
+    S, B, T, _, _, n_moves, _ = g['meta']
+    world = Hex(board=dev(g['world0_board']), seats=dev(g['world0_seats']))
+    for move in range(n_moves):
+        p = f'm{move}_'
+        net = ReplayNetwork(g[p + 'net_logits'], g[p + 'net_v'], DEV)
+        m = MCTS(world, n_nodes=int(T), fused=fused, rng=ReplayRng(g[p + 'rands'], DEV))
+        m.plant_root(t16(g[p + 'tree_logits'][:, 0], DEV), t16(g[p + 'tree_v'][:, 0], DEV))
+        for i in range(T - 1):
+            m.simulate(net)
+            board, seats, _, _ = net.seen[-1]
+            assert np.array_equal(board, g[p + 'net_board'][i]) and np.array_equal(seats, g[p + 'net_seats'][i]), (move, i)
+        compare_search(m, g, p, move)
+        # the root read-out of MCTSAgent (mcts/__init__.py:142-149,221): log of the f16 probabilities
+        r = m.root()
+        want = t16(g[p + 'dec_logits'], 'cpu').float()
+        got = r.logits.float().cpu()
+        fin = torch.isfinite(want)
+        assert torch.equal(torch.isfinite(got), fin) and (got[fin] - want[fin]).abs().max() <= 2e-3   # f16 log, 1 ulp
+        world, trans = world.step(dev(g[p + 'dec_actions']))
+        assert np.array_equal(to_np(trans.rewards), g[p + 'step_rewards']) and np.array_equal(to_np(trans.terminal), g[p + 'step_terminal'])
+
+
+def oracle_search(oracle, board, seats, T, rands, stats=None):
+    s = OracleSearch(oracle, board, seats, T)
+    obs = oracle.hex_observe(board, seats)
+    valid = (obs == 0).all(-1).reshape(board.shape[0], -1)
+    l, v = hash_network_np(board, seats, valid)
+    s.initialize(l, v)
+    for i in range(T - 1):
+        parents, actions = s.descend(rands[i], stats)
+        leaves, nb, ns = s.expand(parents, actions)
+        o = oracle.hex_observe(nb, ns)
+        l, v = hash_network_np(nb, ns, (o == 0).all(-1).reshape(nb.shape[0], -1))
+        s.finish(leaves, l, v)
+    return s
+
+
+def premixed(oracle, B, S, moves, seed):
+    rng = np.random.default_rng(seed)
+    board = np.zeros((B, S, S), np.uint8); seats = np.zeros(B, np.int32)
+    for _ in range(moves):
+        obs = oracle.hex_observe(board, seats)
+        valid = (obs == 0).all(-1).reshape(B, -1)
+        actions = (rng.random(valid.shape) * valid).argmax(-1).astype(np.int32)
+        board, seats, _, _ = oracle.hex_world_step(board, seats, actions)
+    return board, seats
+
+
+@pytest.mark.parametrize('S,B,T', [(9, 4096, 64), (5, 64, 16), (13, 1024, 48), (3, 16384, 8), (11, 333, 32)])
+def test_full_size_search_vs_oracle(oracle, S, B, T):
+    """BASELINE config 2 at its full size (9x9, 4096 envs, 64 nodes) and neighbours: a whole search on the GPU against
+    the oracle-driven search on the host, with a device-independent integer network.  Everything must be identical."""
+    from boardlaw_amd.hex import Hex
+    from boardlaw_amd.mcts import MCTS
+    board, seats = premixed(oracle, B, S, (S * S) // 3, seed=S * 1000 + T)
+    rng = np.random.default_rng(1)
+    rands = rng.random((T - 1, B, T)).astype(np.float16).view(np.uint16)
+    want = oracle_search(oracle, board, seats, T, rands)
+
+    world = Hex(board=torch.from_numpy(board).to(DEV), seats=torch.from_numpy(seats).to(DEV))
+    net = HashNetwork(DEV)
+    m = MCTS(world, n_nodes=T, rng=ReplayRng(rands, DEV), noise_eps=0.)
+    d = net(world)
+    m.plant_root(d.logits, d.v)
+    for _ in range(T - 1):
+        m.simulate(net)
+    for mine, theirs in [(m.tree.children, want.children), (m.tree.parents, want.parents), (m.tree.relation, want.relation),
+                         (m.stats.n, want.n), (m.stats.w, want.w), (m.transitions.rewards, want.rewards),
+                         (m.transitions.terminal, want.terminal), (m.worlds.board, want.boards), (m.worlds.seats, want.seats),
+                         (m.decisions.v, want.v), (m.decisions.logits, want.logits)]:
+        assert np.array_equal(to_np(mine), theirs)
+    assert np.array_equal(bits16(m.root_probs()), want.root_probs())
+    # size-independent invariants of a finished search (every visit adds S=2 to n along its path; root saw them all)
+    n = to_np(m.stats.n)
+    assert (n[:, 0] == 2 * (T - 1)).all()
+    assert (to_np(m.tree.parents)[:, 1:] < np.arange(1, T)[None]).all()
+
+
+def test_toy_worlds_reference_goldens():
+    """boardlaw/mcts/tests.py:242-279 (test_trivial, test_two_player, test_depth, test_multienv) on the generic path."""
+    from boardlaw_amd import validation
+    from boardlaw_amd.mcts import mcts
+    g = gold('toy_envs.npz')
+    agent = validation.ProxyAgent()
+    torch.manual_seed(0)
+    m = mcts(validation.Win.initial(device=DEV), agent, n_nodes=3)
+    np.testing.assert_allclose(m.root().v.float().cpu().numpy(), g['win_v'])
+    m = mcts(validation.WinnerLoser.initial(device=DEV), agent, n_nodes=3)
+    np.testing.assert_allclose(m.root().v.float().cpu().numpy(), g['winnerloser_v'])
+    m = mcts(validation.All.initial(length=3, device=DEV), agent, n_nodes=15, noise_eps=0.)
+    np.testing.assert_allclose(m.root().v.float().cpu().numpy(), g['all_v'])
+    m = mcts(validation.All.initial(n_envs=2, length=3, device=DEV), agent, n_nodes=15, noise_eps=0.)
+    np.testing.assert_allclose(m.root().v.float().cpu().numpy(), g['all2_v'])
+
+
+def test_planted_game_and_agent_surface():
+    """boardlaw/mcts/tests.py:287-309 (planted 3x3 position) + the MCTSAgent output contract (mcts/__init__.py:223-229)."""
+    from boardlaw_amd import hex, validation, networks
+    from boardlaw_amd.mcts import mcts, MCTSAgent
+    torch.manual_seed(3)
+    world = hex.from_string("""
+    wb.
+    bw.
+    wb.
+    """, device=DEV)
+    m = mcts(world, validation.RandomAgent(), n_nodes=63, c_puct=1., noise_eps=0.)
+    probs = m.root().logits.exp()[0]
+    assert (probs[2] > probs[8]) and (probs[5] > probs[7])
+
+    worlds = hex.Hex.initial(64, 5, device=DEV)
+    net = networks.FCModel(worlds.obs_space, worlds.action_space, width=16, depth=4).to(DEV)
+    agent = MCTSAgent(net, n_nodes=16)
+    for _ in range(3):
+        d = agent(worlds)
+        assert d.logits.shape == (64, 25) and d.logits.dtype == torch.half and d.prior.dtype == torch.half
+        assert d.v.shape == (64, 2) and d.v.dtype == torch.half
+        assert d.n_sims.dtype == torch.long and (d.n_sims == 17).all() and d.n_leaves.dtype == torch.long
+        assert d.actions.dtype == torch.long and worlds.valid.gather(1, d.actions[:, None]).all()
+        worlds, _ = worlds.step(d.actions)
+    sd = agent.state_dict()
+    assert 'network.body.1.α' in sd and sd['kwargs.n_nodes'] == 16
+
+
+def test_root_noise_matches_reference_within_f16():
+    """dirichlet_noise + initialize (mcts/__init__.py:13-24,72-80) on the GPU vs the reference's recorded root prior:
+    torch's device exp/log differ from the host's in the last bit, so this one is a tolerance test: 2 f16 ulps."""
+    from boardlaw_amd.mcts import dirichlet_noise
+    g = gold('search_5x5.npz')
+    class Fixed:
+        def __init__(self, d): self.d = d
+        def dirichlet(self, alpha, shape): return self.d.clone()
+    logits = torch.from_numpy(g['m0_net0_logits']).to(DEV)
+    valid = torch.isfinite(logits)
+    out = dirichlet_noise(logits, valid, .25, 10, Fixed(torch.from_numpy(g['m0_dirichlet']).to(DEV))).half()
+    want = t16(g['m0_tree_logits'][:, 0], DEV)
+    fin = torch.isfinite(want)
+    assert torch.equal(torch.isfinite(out), fin)
+    assert (out[fin].float() - want[fin].float()).abs().max() <= 2 * 2**-8
