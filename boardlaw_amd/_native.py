@@ -99,6 +99,19 @@ def exp_table(device):
     return _exp_tables[key]
 
 
+_log_tables = {}
+
+
+def log_table(device):
+    """f16 -> f16 table of the reference's CPU root read-out `r.float().log().half()` (mcts/__init__.py:147) over all
+    65536 binary16 inputs, so the root logits on the GPU carry the reference CPU path's bits, not the device log's."""
+    key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+    if key not in _log_tables:
+        bits = torch.arange(65536, dtype=torch.int32).to(torch.int16)
+        _log_tables[key] = bits.view(torch.half).float().log().half().to(device)
+    return _log_tables[key]
+
+
 def qrange_decode(state):
     host = state.detach().cpu().contiguous()
     out = torch.empty(2, dtype=torch.float32)

@@ -13,6 +13,7 @@
 #include <stdint.h>
 #include <math.h>
 #include <string.h>
+#include <stdlib.h>
 #include "../../include/boardlaw_amd.h"
 
 #pragma clang fp contract(off)
@@ -80,31 +81,80 @@ __device__ __forceinline__ void load_qrange(const uint32_t* qr, float& lo, float
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// policy(): cuda.cu:70-99 + newton_search cuda.cu:35-68, for the group's env b at node t.
-// On return terms[a].x == prob(a) (cuda.cu:23-25) for the final alpha, lch[a] == children[b,t,a].
-// `go` is group-uniform; groups with go == false only keep the wave's barriers company.
+// Per-group LDS carve-up (bytes, every array 16-B aligned):  s[A] f32 | g[A] f32 | child[A] i16 | info[A] u8 | cells[A] u8
+// ------------------------------------------------------------------------------------------------------------------
+__host__ __device__ __forceinline__ int al16(int x) { return (x + 15) & ~15; }
+__host__ __device__ __forceinline__ int lds_bytes(int A, bool with_cells) { return 2 * al16(4 * A) + al16(2 * A) + al16(A) + (with_cells ? al16(A) : 0); }
+
+struct GroupLds {
+    float* s;        // Newton terms lambda*pi/(alpha-q)          == prob(a) once converged (cuda.cu:23-25)
+    float* g;        // derivative terms -lambda*pi/(alpha-q)^2
+    int16_t* child;  // children[b,t,:] of the node being evaluated
+    uint8_t* info;   // per child: bit0 = terminal[b,child], bits1.. = seats[b,child] (prefetched for the next level)
+    uint8_t* cells;  // board scratch for the fused step
+    __device__ __forceinline__ GroupLds(char* base, int A) {
+        s = (float*)base; g = (float*)(base + al16(4 * A)); child = (int16_t*)(base + 2 * al16(4 * A));
+        info = (uint8_t*)(base + 2 * al16(4 * A) + al16(2 * A)); cells = info + al16(A);
+    }
+};
+
+// One serial fold over a = 0..A-1 in the reference's order, leaving the running totals in place of the terms.
+// Lane 0 of the group folds the s terms, lane 1 the g terms (same instruction stream, different array).  Float addition
+// is not associative, so this 1-add-per-action dependent chain IS the algorithm's critical path; everything else in
+// the kernel is arranged to keep other instructions out of it.
+__device__ __forceinline__ float serial_prefix(float* arr, int A) {
+    float acc = 0.f;
+    float4* v4 = (float4*)arr;
+    int a = 0;
+#pragma unroll 4
+    for (; a + 3 < A; a += 4) {
+        float4 x = v4[a >> 2];
+        acc += x.x; x.x = acc;
+        acc += x.y; x.y = acc;
+        acc += x.z; x.z = acc;
+        acc += x.w; x.w = acc;
+        v4[a >> 2] = x;
+    }
+    for (; a < A; a++) { acc += arr[a]; arr[a] = acc; }
+    return acc;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// policy(): cuda.cu:70-99 + newton_search cuda.cu:35-68 + the action draw of descend_kernel cuda.cu:157-176, for the
+// group's env b at node t (whose mover is `seat`).  On return prob[k] == prob(a = k*G+gl) for the final alpha
+// (cuda.cu:23-25), L.child[a] == children[b,t,a], L.info[a] describes that child, and the return value is the sampled
+// edge for uniform r (group-uniform).  `go` is group-uniform; idle groups only keep the wave's barriers company.
 // ------------------------------------------------------------------------------------------------------------------
 template <int G, int K, bool COUNT>
-__device__ __forceinline__ void policy_eval(const Tree& m, int b, int t, bool go, int gl, float lo, float rden,
-                                            float2* terms, int16_t* lch, unsigned long long* counters) {
+__device__ __forceinline__ int policy_eval(const Tree& m, int b, int t, int seat, bool go, int gl, float lo, float rden,
+                                           float r, const GroupLds& L, float (&prob)[K], unsigned long long* counters) {
     const int A = m.A, T = m.T, S = m.S;
     float top[K], q[K];
+    int child[K];
+    uint16_t lb[K];
     int Nloc = 0, nch = 0;
-    const long node = (long)b * T + t;
-    const long row = node * A;
-    int seat = go ? load_seat(m, node) : 0;
+    const long envbase = (long)b * T;
+    const long row = (envbase + t) * A;
+    // round trip 1: the node's two rows, coalesced across the group
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+        const int a = k * G + gl;
+        child[k] = -1; lb[k] = 0;
+        if (go && a < A) { child[k] = m.children[row + a]; lb[k] = m.logits[row + a]; }
+    }
+    // round trip 2: per-child statistics + what the next level needs to know about each child
 #pragma unroll
     for (int k = 0; k < K; k++) {
         const int a = k * G + gl;
         float pi = 0.f, qa = 0.f;
         if (go && a < A) {
-            const int child = m.children[row + a];
-            pi = m.exp_table[m.logits[row + a]];
-            lch[a] = (int16_t)child;
-            if (child > -1) {
-                const long i = (long)b * T + child;
+            pi = m.exp_table[lb[k]];
+            L.child[a] = (int16_t)child[k];
+            if (child[k] > -1) {
+                const long i = envbase + child[k];
                 const float wv = h2f(m.w[i * S + seat]);
                 const int nv = m.n[i];
+                L.info[a] = (uint8_t)((m.terminal[i] ? 1 : 0) | (load_seat(m, i) << 1));
                 const float q32 = wv / ((float)nv + 1.e-4f);
                 qa = h2f(f2h((q32 - lo) / rden));
                 Nloc += nv;
@@ -113,7 +163,7 @@ __device__ __forceinline__ void policy_eval(const Tree& m, int b, int t, bool go
                 Nloc += 1;
             }
         }
-        top[k] = pi; q[k] = qa;
+        top[k] = pi; q[k] = qa; prob[k] = 0.f;
     }
     const int N = gsum<G>(Nloc);
     const float lam = go ? (h2f(m.c_puct[b]) * (float)N) / (float)(unsigned)(N + A) : 0.f;
@@ -127,9 +177,10 @@ __device__ __forceinline__ void policy_eval(const Tree& m, int b, int t, bool go
 
     float err = INFINITY;
     bool conv = !go;      // group-uniform
-    bool broke = !go;
     int iters = 0;
-    for (int it = 0; it < 100; it++) {
+    for (int it = 0; it < 101; it++) {
+        // iteration 100 only happens for groups that ran out of Newton steps: their alpha moved after the last fold
+        // (cuda.cu:48-65), so the probabilities are evaluated once more at the final alpha for the draw.
         if (!__any(!conv)) break;
         if (!conv) {
 #pragma unroll
@@ -137,43 +188,43 @@ __device__ __forceinline__ void policy_eval(const Tree& m, int b, int t, bool go
                 const int a = k * G + gl;
                 if (a < A) {
                     const float bot = alpha - q[k];
-                    terms[a] = make_float2(top[k] / bot, (-top[k]) / (bot * bot));
+                    prob[k] = top[k] / bot;
+                    L.s[a] = prob[k];
+                    L.g[a] = (-top[k]) / (bot * bot);
                 }
             }
         }
         __syncthreads();
-        float Ssum = 0.f, gsum_ = 0.f;
-        if (!conv && gl == 0) {
-            const float4* t4 = (const float4*)terms;
-            int a = 0;
-#pragma unroll 8
-            for (; a + 1 < A; a += 2) {
-                const float4 x = t4[a >> 1];
-                Ssum += x.x; gsum_ += x.y;
-                Ssum += x.z; gsum_ += x.w;
-            }
-            if (a < A) { const float2 x = terms[a]; Ssum += x.x; gsum_ += x.y; }
-        }
-        Ssum = __shfl(Ssum, 0, G);
-        gsum_ = __shfl(gsum_, 0, G);
+        float acc = 0.f;
+        if (!conv && gl < 2) acc = serial_prefix(gl == 0 ? L.s : L.g, A);
+        const float Ssum = __shfl(acc, 0, G), gsum_ = __shfl(acc, 1, G);
         if (!conv) {
-            iters++;
-            const float ne = Ssum - 1.f;
-            if ((ne < 1e-3f) || (err == ne)) { conv = true; broke = true; }
-            else { alpha -= ne / gsum_; err = ne; }
+            if (it == 100) { conv = true; }
+            else {
+                iters++;
+                const float ne = Ssum - 1.f;
+                if ((ne < 1e-3f) || (err == ne)) { conv = true; }
+                else { alpha -= ne / gsum_; err = ne; }
+            }
         }
         __syncthreads();
     }
-    // 100 iterations without a break leave alpha updated past the last evaluated terms (cuda.cu:48-65): refresh.
-    if (__any(!broke)) {
-        if (!broke) {
+    // The draw, cuda.cu:157-176: first a (ascending) with prob > 0 and running total >= r, else the last a with prob > 0.
+    // L.s now holds the running totals in the reference's summation order; every lane tests its own actions.
+    int first = 0x7fffffff, last = -1;
 #pragma unroll
-            for (int k = 0; k < K; k++) {
-                const int a = k * G + gl;
-                if (a < A) { const float bot = alpha - q[k]; terms[a] = make_float2(top[k] / bot, 0.f); }
-            }
+    for (int k = 0; k < K; k++) {
+        const int a = k * G + gl;
+        if (go && a < A) {
+            const bool pos = prob[k] > 0.f;
+            if (pos && L.s[a] >= r && a < first) first = a;
+            if (pos) last = a;
         }
-        __syncthreads();
+    }
+#pragma unroll
+    for (int msk = G / 2; msk > 0; msk >>= 1) {
+        first = min(first, __shfl_xor(first, msk, G));
+        last = max(last, __shfl_xor(last, msk, G));
     }
     if (COUNT && go) {
         const int nc = gsum<G>(nch);
@@ -183,45 +234,41 @@ __device__ __forceinline__ void policy_eval(const Tree& m, int b, int t, bool go
             atomicAdd(&counters[2], (unsigned long long)iters);
         }
     }
+    return first != 0x7fffffff ? first : last;
 }
 
 // descend_kernel's per-env loop, cuda.cu:138-182.  Returns group-uniform (parent, action, next) where next ==
 // children[b,parent,action] (-1 for an unexpanded edge, a terminal node's id otherwise).
 template <int G, int K, bool COUNT>
 __device__ __forceinline__ void descend_group(const Tree& m, int b, bool act, int gl, const uint16_t* rands,
-                                              float2* terms, int16_t* lch, unsigned long long* counters,
+                                              const GroupLds& L, unsigned long long* counters,
                                               int& parent_out, int& action_out, int& next_out) {
     float lo, hi;
     load_qrange(m.qrange, lo, hi);
     const float rden = hi - lo + 1.e-4f;
+    const long envbase = (long)b * m.T;
     int t = 0, parent = 0, action = -1;
-    while (true) {
-        bool go = act && (t != -1);
-        if (go) go = !m.terminal[(long)b * m.T + t];
+    bool term = false;
+    int seat = 0;
+    if (act) { term = m.terminal[envbase]; seat = load_seat(m, envbase); }
+    // A root-to-leaf path in a T-slot tree has at most T nodes; the bound only matters for a corrupted tree, where the
+    // reference's while(true) (cuda.cu:149) would spin forever.
+    for (int depth = 0; depth < m.T; depth++) {
+        const bool go = act && (t != -1) && !term;
         if (!__any(go)) break;
-        policy_eval<G, K, COUNT>(m, b, t, go, gl, lo, rden, terms, lch, counters);
-        int nxt = -1;
-        if (go && gl == 0) {
-            // inverse-CDF walk in ascending a, cuda.cu:157-176
-            const float r = h2f(rands[(long)b * m.T + t]);
-            float total = 0.f;
-            int valid = -1;
-            action = -1;
-            for (int a = 0; a < m.A; a++) {
-                const float p = terms[a].x;
-                total += p;
-                if ((p > 0) && (total >= r)) { action = a; break; }
-                else if (p > 0) { valid = a; }
-            }
-            action = (action >= 0) ? action : valid;
-            nxt = (action >= 0) ? (int)lch[action] : -1;
-        }
-        action = __shfl(action, 0, G);
-        nxt = __shfl(nxt, 0, G);
+        const float r = go ? h2f(rands[envbase + t]) : 0.f;
+        float prob[K];
+        const int a = policy_eval<G, K, COUNT>(m, b, t, seat, go, gl, lo, rden, r, L, prob, counters);
         if (go) {
+            action = a;
             parent = t;
-            t = nxt;
-            if (action < 0) act = false;   // reference would index children[b][t][-1]; unreachable with a finite logit
+            if (action < 0) { act = false; }   // reference would index children[b][t][-1]; unreachable with a finite logit
+            else {
+                t = L.child[action];
+                const int info = L.info[action];
+                term = (t != -1) && (info & 1);
+                seat = info >> 1;
+            }
         }
         __syncthreads();
     }
@@ -230,32 +277,36 @@ __device__ __forceinline__ void descend_group(const Tree& m, int b, bool act, in
 
 template <int G, int K, bool COUNT>
 __global__ void __launch_bounds__(BL_WAVE) descend_kernel(Tree m, const uint16_t* rands, int16_t* parents,
-                                                          int16_t* actions, int lds_terms, unsigned long long* counters) {
+                                                          int16_t* actions, unsigned long long* counters) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int grp = threadIdx.x / G, gl = threadIdx.x % G;
     const int b = blockIdx.x * (BL_WAVE / G) + grp;
-    char* base = smem + (size_t)grp * (lds_terms + ((2 * m.A + 15) & ~15));
-    float2* terms = (float2*)base;
-    int16_t* lch = (int16_t*)(base + lds_terms);
+    const GroupLds L(smem + (size_t)grp * lds_bytes(m.A, false), m.A);
     int parent, action, nxt;
-    descend_group<G, K, COUNT>(m, b, b < m.B, gl, rands, terms, lch, counters, parent, action, nxt);
+    descend_group<G, K, COUNT>(m, b, b < m.B, gl, rands, L, counters, parent, action, nxt);
     if (b < m.B && gl == 0) { parents[b] = (int16_t)parent; actions[b] = (int16_t)action; }
 }
 
 // root_kernel, cuda.cu:107-118
 template <int G, int K>
-__global__ void __launch_bounds__(BL_WAVE) root_kernel(Tree m, uint16_t* probs, int lds_terms) {
+__global__ void __launch_bounds__(BL_WAVE) root_kernel(Tree m, uint16_t* probs) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int grp = threadIdx.x / G, gl = threadIdx.x % G;
     const int b = blockIdx.x * (BL_WAVE / G) + grp;
-    char* base = smem + (size_t)grp * (lds_terms + ((2 * m.A + 15) & ~15));
-    float2* terms = (float2*)base;
-    int16_t* lch = (int16_t*)(base + lds_terms);
+    const GroupLds L(smem + (size_t)grp * lds_bytes(m.A, false), m.A);
     float lo, hi;
     load_qrange(m.qrange, lo, hi);
     const bool go = b < m.B;
-    policy_eval<G, K, false>(m, b, 0, go, gl, lo, hi - lo + 1.e-4f, terms, lch, nullptr);
-    if (go) for (int a = gl; a < m.A; a += G) probs[(long)b * m.A + a] = f2h(terms[a].x);
+    const int seat = go ? load_seat(m, (long)b * m.T) : 0;
+    float prob[K];
+    policy_eval<G, K, false>(m, b, 0, seat, go, gl, lo, hi - lo + 1.e-4f, 2.f, L, prob, nullptr);
+    if (go) {
+#pragma unroll
+        for (int k = 0; k < K; k++) {
+            const int a = k * G + gl;
+            if (a < m.A) probs[(long)b * m.A + a] = f2h(prob[k]);
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -420,17 +471,14 @@ struct Search {
 template <int G, int K, bool COUNT>
 __global__ void __launch_bounds__(BL_WAVE) sim_expand_kernel(Search s, int sim, const uint16_t* rands, int16_t* leaves_out,
                                                              float2* obs_out, uint8_t* valid_out, int32_t* leaf_seats_out,
-                                                             int lds_terms, unsigned long long* counters) {
+                                                             unsigned long long* counters) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int S = s.S, A = S * S, T = s.T;
     const int grp = threadIdx.x / G, gl = threadIdx.x % G;
     const int b = blockIdx.x * (BL_WAVE / G) + grp;
     const bool act = b < s.B;
-    const int lds_ch = (2 * A + 15) & ~15, lds_cells = (A + 15) & ~15;
-    char* base = smem + (size_t)grp * (lds_terms + lds_ch + lds_cells);
-    float2* terms = (float2*)base;
-    int16_t* lch = (int16_t*)(base + lds_terms);
-    uint8_t* cells = (uint8_t*)(base + lds_terms + lds_ch);
+    const GroupLds L(smem + (size_t)grp * lds_bytes(A, true), A);
+    uint8_t* cells = L.cells;
 
     Tree m;
     m.logits = s.logits; m.w = s.w; m.n = s.n; m.c_puct = s.c_puct; m.seats = s.seats; m.terminal = s.terminal;
@@ -438,7 +486,7 @@ __global__ void __launch_bounds__(BL_WAVE) sim_expand_kernel(Search s, int sim, 
     m.B = s.B; m.T = T; m.A = A; m.S = 2; m.seats_i32 = 1;
 
     int parent, action, nxt;
-    descend_group<G, K, COUNT>(m, b, act, gl, rands, terms, lch, counters, parent, action, nxt);
+    descend_group<G, K, COUNT>(m, b, act, gl, rands, L, counters, parent, action, nxt);
     if (action < 0) action = 0;
 
     // leaves = children[envs, parents, actions]; leaves[leaves == -1] = sim   (mcts/__init__.py:117-122)
@@ -543,34 +591,44 @@ __global__ void __launch_bounds__(256) sim_replicate_kernel(Search s, const uint
 // =====================================================================================================================
 using namespace bl;
 
+// Tuning knob for experiments (read once): BL_FORCE_GROUP=8|16|32|64 overrides the heuristic below.
+static int forced_group() {
+    static int g = -1;
+    if (g < 0) { const char* e = getenv("BL_FORCE_GROUP"); g = e ? atoi(e) : 0; }
+    return g;
+}
+
 static int pick_group(int B, int A) {
-    // Smallest group that keeps <= 16 actions per lane, widened while the launch has too few waves to cover the
-    // chip's 1024 SIMDs (256 CUs x 4): lanes idle in the serial fold are cheaper than idle SIMDs.
+    const int f = forced_group();
+    if ((f == 8 || f == 16 || f == 32 || f == 64) && (A + f - 1) / f <= 16) return f;
+    // Smallest group that keeps <= 16 actions per lane, widened while the launch has fewer than 4 waves for each of
+    // the chip's 1024 SIMDs (256 CUs x 4): a descent is one long dependent chain (loads -> Newton folds -> draw), so
+    // what hides its latency is other waves on the SIMD; lanes idling in the serial fold are the cheaper waste.
     int G = 8;
     while (G < 64 && (A + G - 1) / G > 16) G *= 2;
-    while (G < 64 && (long)B * G / 64 < 1024) G *= 2;
+    while (G < 64 && (long)B * G / 64 < 4096) G *= 2;
     return G;
 }
 
 static int pick_k(int A, int G) {
     const int need = (A + G - 1) / G;
-    const int ks[4] = {2, 6, 12, 16};
-    for (int i = 0; i < 4; i++) if (need <= ks[i]) return ks[i];
+    const int ks[7] = {2, 3, 4, 6, 8, 12, 16};
+    for (int i = 0; i < 7; i++) if (need <= ks[i]) return ks[i];
     return -1;
 }
 
 static int check_launch() { return hipGetLastError() == hipSuccess ? BL_OK : BL_ELAUNCH; }
 
+#define BL_DISPATCH_K(g, K, CALL)                                                                    \
+    switch (K) {                                                                                     \
+        case 2: { CALL(g, 2); } break;   case 3: { CALL(g, 3); } break;   case 4: { CALL(g, 4); } break; \
+        case 6: { CALL(g, 6); } break;   case 8: { CALL(g, 8); } break;   case 12: { CALL(g, 12); } break; \
+        case 16: { CALL(g, 16); } break; default: return BL_ETOOBIG;                                 \
+    }
 #define BL_DISPATCH_GK(G, K, CALL)                                                                   \
-    switch ((G) * 100 + (K)) {                                                                       \
-        case 802: { CALL(8, 2); } break;   case 806: { CALL(8, 6); } break;                           \
-        case 812: { CALL(8, 12); } break;  case 816: { CALL(8, 16); } break;                          \
-        case 1602: { CALL(16, 2); } break; case 1606: { CALL(16, 6); } break;                         \
-        case 1612: { CALL(16, 12); } break; case 1616: { CALL(16, 16); } break;                       \
-        case 3202: { CALL(32, 2); } break; case 3206: { CALL(32, 6); } break;                         \
-        case 3212: { CALL(32, 12); } break; case 3216: { CALL(32, 16); } break;                       \
-        case 6402: { CALL(64, 2); } break; case 6406: { CALL(64, 6); } break;                         \
-        case 6412: { CALL(64, 12); } break; case 6416: { CALL(64, 16); } break;                       \
+    switch (G) {                                                                                     \
+        case 8: BL_DISPATCH_K(8, K, CALL) break;    case 16: BL_DISPATCH_K(16, K, CALL) break;        \
+        case 32: BL_DISPATCH_K(32, K, CALL) break;  case 64: BL_DISPATCH_K(64, K, CALL) break;        \
         default: return BL_ETOOBIG;                                                                  \
     }
 
@@ -640,11 +698,10 @@ int bl_mcts_descend(const void* logits, const void* w, const int16_t* n, const v
     Tree m{(const uint16_t*)logits, (const uint16_t*)w, n, (const uint16_t*)c_puct, seats, terminal, children, qr,
            exp_table, B, T, A, S, 0};
     const int G = pick_group(B, A), K = pick_k(A, G);
-    const int lds_terms = (8 * A + 15) & ~15;
-    const int per = lds_terms + ((2 * A + 15) & ~15);
+    const int per = lds_bytes(A, false);
     const int blocks = (B + 64 / G - 1) / (64 / G);
 #define CALL(g, k) hipLaunchKernelGGL((descend_kernel<g, k, false>), dim3(blocks), dim3(64), (size_t)per * (64 / g), \
-                                      (hipStream_t)stream, m, (const uint16_t*)rands, parents, actions, lds_terms, nullptr)
+                                      (hipStream_t)stream, m, (const uint16_t*)rands, parents, actions, nullptr)
     BL_DISPATCH_GK(G, K, CALL)
 #undef CALL
     return check_launch();
@@ -659,11 +716,10 @@ int bl_mcts_root(const void* logits, const void* w, const int16_t* n, const void
     Tree m{(const uint16_t*)logits, (const uint16_t*)w, n, (const uint16_t*)c_puct, seats, terminal, children, qr,
            exp_table, B, T, A, S, 0};
     const int G = pick_group(B, A), K = pick_k(A, G);
-    const int lds_terms = (8 * A + 15) & ~15;
-    const int per = lds_terms + ((2 * A + 15) & ~15);
+    const int per = lds_bytes(A, false);
     const int blocks = (B + 64 / G - 1) / (64 / G);
 #define CALL(g, k) hipLaunchKernelGGL((root_kernel<g, k>), dim3(blocks), dim3(64), (size_t)per * (64 / g), \
-                                      (hipStream_t)stream, m, (uint16_t*)probs, lds_terms)
+                                      (hipStream_t)stream, m, (uint16_t*)probs)
     BL_DISPATCH_GK(G, K, CALL)
 #undef CALL
     return check_launch();
@@ -720,18 +776,17 @@ static int sim_expand_impl(const bl_search_t* s, int sim, const void* rands, int
     if (!rands || !leaves || !obs || !valid || !leaf_seats || sim < 1 || sim >= s->T) return BL_EINVAL;
     const int A = s->boardsize * s->boardsize;
     const int G = pick_group(s->B, A), K = pick_k(A, G);
-    const int lds_terms = (8 * A + 15) & ~15;
-    const int per = lds_terms + ((2 * A + 15) & ~15) + ((A + 15) & ~15);
+    const int per = lds_bytes(A, true);
     const int blocks = (s->B + 64 / G - 1) / (64 / G);
     Search ss = to_search(s);
     if (counters) {
 #define CALL(g, k) hipLaunchKernelGGL((sim_expand_kernel<g, k, true>), dim3(blocks), dim3(64), (size_t)per * (64 / g), \
-                                      (hipStream_t)stream, ss, sim, (const uint16_t*)rands, leaves, (float2*)obs, valid, leaf_seats, lds_terms, counters)
+                                      (hipStream_t)stream, ss, sim, (const uint16_t*)rands, leaves, (float2*)obs, valid, leaf_seats, counters)
         BL_DISPATCH_GK(G, K, CALL)
 #undef CALL
     } else {
 #define CALL(g, k) hipLaunchKernelGGL((sim_expand_kernel<g, k, false>), dim3(blocks), dim3(64), (size_t)per * (64 / g), \
-                                      (hipStream_t)stream, ss, sim, (const uint16_t*)rands, leaves, (float2*)obs, valid, leaf_seats, lds_terms, nullptr)
+                                      (hipStream_t)stream, ss, sim, (const uint16_t*)rands, leaves, (float2*)obs, valid, leaf_seats, nullptr)
         BL_DISPATCH_GK(G, K, CALL)
 #undef CALL
     }
@@ -768,11 +823,10 @@ int bl_sim_root(const bl_search_t* s, int sim, void* probs, bl_stream_t stream) 
     Tree m{(const uint16_t*)s->logits, (const uint16_t*)s->w, s->n, (const uint16_t*)s->c_puct, s->seats, s->terminal,
            s->children, s->qrange + 2 * BL_QSLOTS * sim, s->exp_table, s->B, s->T, A, 2, 1};
     const int G = pick_group(s->B, A), K = pick_k(A, G);
-    const int lds_terms = (8 * A + 15) & ~15;
-    const int per = lds_terms + ((2 * A + 15) & ~15);
+    const int per = lds_bytes(A, false);
     const int blocks = (s->B + 64 / G - 1) / (64 / G);
 #define CALL(g, k) hipLaunchKernelGGL((root_kernel<g, k>), dim3(blocks), dim3(64), (size_t)per * (64 / g), \
-                                      (hipStream_t)stream, m, (uint16_t*)probs, lds_terms)
+                                      (hipStream_t)stream, m, (uint16_t*)probs)
     BL_DISPATCH_GK(G, K, CALL)
 #undef CALL
     return check_launch();

@@ -218,8 +218,11 @@ class MCTS:
 
     def root(self):
         r = self.root_probs()
+        # the reference takes r.log() on the device and r.float().log().half() on the host (mcts/__init__.py:147);
+        # here the host's values are looked up per f16 bit pattern so both paths agree bit for bit
+        logits = _native.log_table(r.device)[r.view(torch.int16).long() & 0xffff]
         return arrdict.arrdict(
-            logits=r.log() if r.device.type == 'cuda' else r.float().log().half(),
+            logits=logits,
             prior=self.decisions.logits[:, 0],
             v=self.decisions.v[:, 0])
 

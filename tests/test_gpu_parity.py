@@ -202,10 +202,8 @@ def test_whole_search_replay(name, fused):
         compare_search(m, g, p, move)
         # the root read-out of MCTSAgent (mcts/__init__.py:142-149,221): log of the f16 probabilities
         r = m.root()
-        want = t16(g[p + 'dec_logits'], 'cpu').float()
-        got = r.logits.float().cpu()
-        fin = torch.isfinite(want)
-        assert torch.equal(torch.isfinite(got), fin) and (got[fin] - want[fin]).abs().max() <= 2e-3   # f16 log, 1 ulp
+        assert np.array_equal(bits16(r.logits), g[p + 'dec_logits']), move
+        assert np.array_equal(bits16(r.prior), g[p + 'dec_prior']) and np.array_equal(bits16(r.v), g[p + 'dec_v']), move
         world, trans = world.step(dev(g[p + 'dec_actions']))
         assert np.array_equal(to_np(trans.rewards), g[p + 'step_rewards']) and np.array_equal(to_np(trans.terminal), g[p + 'step_terminal'])
 
