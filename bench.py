@@ -108,6 +108,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--envs', type=int, default=ENVS, help='envs per GPU (the metric is quoted at 4096)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--eager', action='store_true', help='launch kernel by kernel instead of replaying a HIP graph per move')
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', 0)); world = int(os.environ.get('WORLD_SIZE', 1))
@@ -131,7 +132,7 @@ def main():
     net = networks.FCModel(worlds.obs_space, worlds.action_space, width=WIDTH, depth=DEPTH).cuda()
     worlds = premix(worlds, BOARD * BOARD // 3, gen)
     torch.manual_seed(1 + rank)
-    agent = MCTSAgent(net, n_nodes=NODES)
+    agent = MCTSAgent(net, n_nodes=NODES, graph=not args.eager)
 
     timer = TimedExpand(lib)
     lib.bl_sim_expand = timer
@@ -151,7 +152,7 @@ def main():
         torch.cuda.synchronize()
 
     barrier()
-    timer.on = True
+    timer.on = args.eager          # graph replays cannot carry per-launch events; see the probe below
     t0 = time.perf_counter()
     for _ in range(args.steps):
         worlds = move(worlds)
@@ -168,6 +169,14 @@ def main():
 
     if rank == 0:
         A, S = BOARD * BOARD, 2
+        if not args.eager:
+            # the same moves launched kernel by kernel, only to bracket every bl_sim_expand launch with HIP events
+            probe = MCTSAgent(net, n_nodes=NODES, graph=False)
+            timer.on = True
+            for _ in range(min(args.steps, 5)):
+                worlds, _ = worlds.step(probe(worlds).actions, check=False)
+            torch.cuda.synchronize()
+            timer.on = False
         lib.bl_sim_expand = timer.orig
         d, k, its = tree_statistics(worlds, net, NODES)
         kernel_us = timer.mean_us()
@@ -179,14 +188,15 @@ def main():
             'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': f'9x9 Hex, {args.envs} envs/GPU x {NODES} sims/move, FCModel {WIDTH}x{DEPTH} fp16 autocast '
                                    '(BASELINE config 2); step = one self-play move of the batch',
-                       'envs_per_gpu': args.envs, 'nodes': NODES, 'boardsize': BOARD, 'parallelism': f'replicas x{world}',
+                       'envs_per_gpu': args.envs, 'nodes': NODES, 'boardsize': BOARD, 'parallelism': f'replicas x{world}', 'launch': 'eager' if args.eager else 'hip-graph per move',
                        'd_policy_evals_per_descent': round(d, 3), 'k_child_lookups_per_descent': round(k, 3),
                        'newton_iters_per_eval': round(its, 3),
                        'bytes_per_sim_whole_path': round(total_bytes_per_sim(A, S, NODES, d, k), 1),
                        'hbm_frac_whole_path': total_bytes_per_sim(A, S, NODES, d, k) * value / world / (HBM_PEAK_GBS * 1e9)},
             'roofline': {'bound': 'hbm', 'kernel': 'bl::sim_expand_kernel', 'achieved': achieved, 'peak': HBM_PEAK_GBS,
                          'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS, 'traffic': None,
-                         'kernel_us': kernel_us, 'bytes_per_launch': per_launch, 'launches_timed': len(timer.pairs)},
+                         'kernel_us': kernel_us, 'bytes_per_launch': per_launch, 'launches_timed': len(timer.pairs),
+                         'timing': 'HIP events around every launch ' + ('inside the timed region' if args.eager else 'in an eager re-run of the same moves right after the timed (graph-replay) region')},
         }
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline()

@@ -232,6 +232,9 @@ __device__ __forceinline__ int policy_eval(const Tree& m, int b, int t, int seat
             atomicAdd(&counters[0], 1ull);
             atomicAdd(&counters[1], (unsigned long long)nc);
             atomicAdd(&counters[2], (unsigned long long)iters);
+            // per-env totals for this launch: levels, Newton iterations, worst level
+            unsigned long long* e = counters + 3 + 3 * (long)b;
+            e[0] += 1; e[1] += iters; if ((unsigned long long)iters > e[2]) e[2] = iters;
         }
     }
     return first != 0x7fffffff ? first : last;
@@ -567,21 +570,49 @@ __global__ void __launch_bounds__(BL_WAVE) sim_backup_kernel(Search s, int sim, 
     qrange_publish(s.qrange + 2 * BL_QSLOTS * (sim + 1), nmin, vmax, blockIdx.x % BL_QSLOTS);
 }
 
-__global__ void __launch_bounds__(256) sim_replicate_kernel(Search s, const uint8_t* root_board, const int32_t* root_seats) {
-    const int A = s.S * s.S;
-    const long total = (long)s.B * s.T * A;
+// Fills nbytes at p (16-B aligned, as torch allocations are) with a repeating 16-bit pattern; whole grid cooperates.
+__device__ __forceinline__ void grid_fill(void* p, size_t nbytes, uint16_t pat) {
+    const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x, nth = (size_t)gridDim.x * blockDim.x;
+    const uint32_t w = (uint32_t)pat | ((uint32_t)pat << 16);
+    const uint4 v = make_uint4(w, w, w, w);
+    const size_t n16 = nbytes / 16;
+    for (size_t i = tid; i < n16; i += nth) ((uint4*)p)[i] = v;
+    for (size_t i = n16 * 16 + tid; i < nbytes; i += nth) ((uint8_t*)p)[i] = (uint8_t)((i & 1) ? (pat >> 8) : pat);
+}
+
+// MCTS.__init__ (mcts/__init__.py:43-67) as ONE kernel.  (hipMemsetAsync nodes captured into a HIP graph were observed
+// to execute on the first replay only with the ROCm runtime PyTorch bundles, so the reset is a kernel, not memsets.)
+__global__ void __launch_bounds__(256) sim_init_kernel(Search s, const uint8_t* root_board, const int32_t* root_seats) {
+    const size_t B = s.B, T = s.T, A = (size_t)s.S * s.S;
+    grid_fill(s.children, B * T * A * 2, 0xffff);
+    grid_fill(s.parents, B * T * 2, 0xffff);
+    grid_fill(s.relation, B * T * 2, 0xffff);
+    grid_fill(s.logits, B * T * A * 2, 0x7e00);   // f16 NaN, mcts/__init__.py:56
+    grid_fill(s.v, B * T * 2 * 2, 0x7e00);
+    grid_fill(s.w, B * T * 2 * 2, 0);
+    grid_fill(s.n, B * T * 2, 0);
+    grid_fill(s.rewards, B * T * 2 * 2, 0);
+    grid_fill(s.terminal, B * T, 0);
+    grid_fill(s.qrange, (T + 1) * 2 * BL_QSLOTS * sizeof(uint32_t), 0);
+    const long total = (long)(B * T * A);
     for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
-        const long node = idx / A;
-        const int a = (int)(idx - node * A);
-        const long b = node / s.T;
+        const long node = idx / (long)A;
+        const int a = (int)(idx - node * (long)A);
+        const long b = node / (long)T;
         s.boards[idx] = root_board[b * A + a];
         if (a == 0) s.seats[node] = root_seats[b];
     }
-    // descend #1 sees the untouched stats: every q is 0/1e-4 = 0, so its range is {0, 0}
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        s.qrange[2 * BL_QSLOTS * 1 + 0] = ~enc(0.f);
-        s.qrange[2 * BL_QSLOTS * 1 + 1] = enc(0.f);
-    }
+}
+
+// descend #1 sees the untouched stats: every q is 0/1e-4 = 0, so its range is {0, 0}.  Separate launch: it must land
+// after the grid-wide zeroing of qrange above.
+__global__ void sim_init_qrange_kernel(Search s) {
+    s.qrange[2 * BL_QSLOTS * 1 + 0] = ~enc(0.f);
+    s.qrange[2 * BL_QSLOTS * 1 + 1] = enc(0.f);
+}
+
+__global__ void __launch_bounds__(256) zero_words_kernel(uint32_t* p, int n) {
+    for (int i = threadIdx.x; i < n; i += blockDim.x) p[i] = 0;
 }
 
 }  // namespace bl
@@ -674,7 +705,7 @@ int bl_qrange_decode(const uint32_t* st, float* mm) {
 int bl_mcts_qrange(const void* w, const int16_t* n, int B, int T, int S, uint32_t* st, bl_stream_t stream) {
     if (!w || !n || !st || B <= 0 || T <= 0 || S <= 0) return BL_EINVAL;
     hipStream_t hs = (hipStream_t)stream;
-    if (hipMemsetAsync(st, 0, 2 * BL_QSLOTS * sizeof(uint32_t), hs) != hipSuccess) return BL_ELAUNCH;
+    hipLaunchKernelGGL(zero_words_kernel, dim3(1), dim3(128), 0, hs, st, 2 * BL_QSLOTS);
     const long nodes = (long)B * T;
     int blocks = (int)((nodes + 255) / 256); if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(qrange_kernel, dim3(blocks), dim3(256), 0, hs, (const uint16_t*)w, n, nodes, S, st);
@@ -837,21 +868,8 @@ int bl_sim_init(const bl_search_t* s, const uint8_t* root_board, const int32_t* 
     if (rc) return rc;
     if (!root_board || !root_seats) return BL_EINVAL;
     hipStream_t hs = (hipStream_t)stream;
-    const size_t B = s->B, T = s->T, A = (size_t)s->boardsize * s->boardsize;
-    bool ok = true;
-    ok &= hipMemsetAsync(s->children, 0xff, B * T * A * 2, hs) == hipSuccess;
-    ok &= hipMemsetAsync(s->parents, 0xff, B * T * 2, hs) == hipSuccess;
-    ok &= hipMemsetAsync(s->relation, 0xff, B * T * 2, hs) == hipSuccess;
-    ok &= hipMemsetD16Async((hipDeviceptr_t)s->logits, 0x7e00, B * T * A, hs) == hipSuccess;   // f16 NaN, mcts/__init__.py:56
-    ok &= hipMemsetD16Async((hipDeviceptr_t)s->v, 0x7e00, B * T * 2, hs) == hipSuccess;
-    ok &= hipMemsetAsync(s->w, 0, B * T * 2 * 2, hs) == hipSuccess;
-    ok &= hipMemsetAsync(s->n, 0, B * T * 2, hs) == hipSuccess;
-    ok &= hipMemsetAsync(s->rewards, 0, B * T * 2 * 2, hs) == hipSuccess;
-    ok &= hipMemsetAsync(s->terminal, 0, B * T, hs) == hipSuccess;
-    ok &= hipMemsetAsync(s->qrange, 0, (T + 1) * 2 * BL_QSLOTS * sizeof(uint32_t), hs) == hipSuccess;
-    if (!ok) return BL_ELAUNCH;
-    long blocks = (long)((B * T * A + 255) / 256); if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(sim_replicate_kernel, dim3((unsigned)blocks), dim3(256), 0, hs, to_search(s), root_board, root_seats);
+    hipLaunchKernelGGL(sim_init_kernel, dim3(2048), dim3(256), 0, hs, to_search(s), root_board, root_seats);
+    hipLaunchKernelGGL(sim_init_qrange_kernel, dim3(1), dim3(1), 0, hs, to_search(s));
     return check_launch();
 }
 

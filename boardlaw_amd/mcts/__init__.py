@@ -28,14 +28,16 @@ from . import cuda
 class TorchRng:
     """The reference's three random draws, in its shapes/dtypes/order, from torch's default generator."""
 
+    # validate_args=False: the reference's default argument validation costs a device->host sync per draw and does not
+    # touch the generator, so the draws are the same.
     def dirichlet(self, alpha, shape):
-        return torch.distributions.Dirichlet(alpha).sample(shape)          # mcts/__init__.py:16-18
+        return torch.distributions.Dirichlet(alpha, validate_args=False).sample(shape)     # mcts/__init__.py:16-18
 
     def rand_like(self, x):
         return torch.rand_like(x)                                           # mcts/cpp/cuda.cu:191
 
     def categorical(self, logits):
-        return torch.distributions.Categorical(logits=logits).sample()      # mcts/__init__.py:221
+        return torch.distributions.Categorical(logits=logits, validate_args=False).sample()  # mcts/__init__.py:221
 
 
 def dirichlet_noise(logits, valid, eps, alpha_scale=10, rng=None):
@@ -101,7 +103,7 @@ class MCTS:
             self._obs = e(B, bs, bs, 2, dtype=torch.float)
             self._valid = e(B, A, dtype=torch.bool)
             self._leaf_seats = e(B, dtype=torch.int)
-            self.counters = torch.zeros(3, dtype=torch.int64, device=dev) if count else None
+            self.counters = torch.zeros(3 + 3 * B, dtype=torch.int64, device=dev) if count else None
             self._search = _native.Search(
                 logits=self.decisions.logits.data_ptr(), v=self.decisions.v.data_ptr(), w=self.stats.w.data_ptr(),
                 n=self.stats.n.data_ptr(), children=self.tree.children.data_ptr(), parents=self.tree.parents.data_ptr(),
@@ -240,13 +242,20 @@ def mcts(worlds, network, **kwargs):
 
 class MCTSAgent:
     """mcts/__init__.py:209-241.  Output arrdict: logits (B,A) f16, prior (B,A) f16, n_sims (B) i64, n_leaves (B) i64,
-    v (B,S) f16, actions (B) i64."""
+    v (B,S) f16, actions (B) i64.
 
-    def __init__(self, network, **kwargs):
+    graph=True (Hex on the GPU only) captures one whole move -- tree reset, root evaluation + noise, the T-1
+    expand/network/backup rounds, root read-out and the action draw -- into a HIP graph per (batch size, board size,
+    eval) and replays it: the search has no host-side decision in it (the fused path keeps `sim` on the host and never
+    syncs), so replay removes every launch gap.  Random draws come from torch's generator exactly as in eager mode."""
+
+    def __init__(self, network, graph=False, **kwargs):
         self.network = network
         self.kwargs = kwargs
+        self.graph = graph
+        self._graphs = {}
 
-    def __call__(self, world, value=True, eval=False, **kwargs):
+    def _move(self, world, eval, kwargs):
         m = mcts(world, self.network, **{**self.kwargs, **kwargs})
         r = m.root()
         actions = r.logits.argmax(-1) if eval else m.rng.categorical(r.logits.float())
@@ -258,13 +267,51 @@ class MCTSAgent:
             v=r.v,
             actions=actions).clone()
 
+    def __call__(self, world, value=True, eval=False, **kwargs):
+        if not self.graph or kwargs or world.device.type != 'cuda':
+            return self._move(world, eval, kwargs)
+        key = (type(world), world.n_envs, world.boardsize, bool(eval), world.device)
+        if key not in self._graphs:
+            self._graphs[key] = _GraphedMove(self, world, eval)
+        return self._graphs[key](world)
+
     def load_state_dict(self, sd):
         self.network.load_state_dict({k[len('network.'):]: v for k, v in sd.items() if k.startswith('network.')})
         self.kwargs.update({k[len('kwargs.'):]: v for k, v in sd.items() if k.startswith('kwargs.')})
+        self._graphs = {}
 
     def state_dict(self):
         return {**{f'network.{k}': v for k, v in self.network.state_dict().items()},
                 **{f'kwargs.{k}': v for k, v in self.kwargs.items()}}
+
+
+class _GraphedMove:
+    """One captured move for a fixed (world type, B, boardsize, eval).  Inputs are copied into static buffers, the
+    graph is replayed, outputs are cloned out.  Network parameters are read in place, so training steps between
+    replays are seen."""
+
+    def __init__(self, agent, world, eval):
+        dev = world.device
+        self.board, self.seats = world.board.clone(), world.seats.clone()
+        kind = type(world)
+
+        def run():
+            return agent._move(kind(board=self.board, seats=self.seats), eval, {})
+
+        with torch.cuda.device(dev):
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                run()                                   # warm-up: builds lookup tables, lets hipBLASLt pick kernels
+            torch.cuda.current_stream().wait_stream(side)
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph):
+                self.out = run()
+
+    def __call__(self, world):
+        self.board.copy_(world.board); self.seats.copy_(world.seats)
+        self.graph.replay()
+        return self.out.clone()
 
 
 class DummyAgent:

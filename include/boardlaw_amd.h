@@ -46,7 +46,7 @@ int bl_exp_table_host(float* host_table /* 65536 floats, HOST memory */);
  * qrange_state: BL_QRANGE_WORDS x u32, device: 64 slots of {max of ~enc(q), max of enc(q)} over the slot's share of
  * the B*T*S values q = f32(w)/(f32(n)+1e-4f); enc = the order-preserving float->u32 map.  Spreading the atomics
  * over 64 addresses keeps the reduction off a single L2 atomic unit; consumers max-reduce the 64 slots in one wave
- * load.  bl_mcts_qrange zeroes the state itself (memset node) and reduces into it; shards that want the reference's
+ * load.  bl_mcts_qrange zeroes the state itself (a kernel, not a memset node) and reduces into it; shards that want the reference's
  * *global* normalisation all-reduce(MAX) the words across ranks.  bl_qrange_decode turns a HOST copy into {min,max}. */
 int bl_mcts_qrange(const void* w /*f16 (B,T,S)*/, const int16_t* n /*(B,T)*/, int B, int T, int S,
                    uint32_t* qrange_state, bl_stream_t stream);
@@ -131,9 +131,9 @@ int bl_sim_root(const bl_search_t* s, int sim, void* probs_out /*f16 (B,A)*/, bl
 int bl_sim_init(const bl_search_t* s, const uint8_t* root_board /*(B,S,S)*/, const int32_t* root_seats /*(B)*/,
                 bl_stream_t stream);
 
-/* Diagnostics for the roofline model: per-launch totals accumulated by bl_sim_expand when `counters`
- * (3 x u64, device, caller-zeroed) is set with bl_sim_expand_counted: [0] policy evaluations (d), [1] expanded-child
- * lookups (k), [2] Newton iterations. */
+/* Diagnostics for the roofline model: bl_sim_expand plus counters accumulated into `counters`
+ * ((3 + 3*B) x u64, device, caller-zeroed): [0] policy evaluations (d), [1] expanded-child lookups (k), [2] Newton
+ * iterations; then per env {levels, Newton iterations, most iterations in one level}. */
 int bl_sim_expand_counted(const bl_search_t* s, int sim, const void* rands, int16_t* leaves_out, float* obs_out,
                           uint8_t* valid_out, int32_t* leaf_seats_out, unsigned long long* counters,
                           bl_stream_t stream);

@@ -324,3 +324,23 @@ def test_root_noise_matches_reference_within_f16():
     fin = torch.isfinite(want)
     assert torch.equal(torch.isfinite(out), fin)
     assert (out[fin].float() - want[fin].float()).abs().max() <= 2 * 2**-8
+
+
+def test_graphed_move_equals_eager_move():
+    """A HIP-graph replay of a whole move must produce exactly what the eager launch sequence produces for the same
+    generator state (same draws, same kernels), move after move."""
+    from boardlaw_amd import hex, networks
+    from boardlaw_amd.mcts import MCTSAgent
+    torch.manual_seed(0)
+    worlds = hex.Hex.initial(256, 5, device=DEV)
+    net = networks.FCModel(worlds.obs_space, worlds.action_space, width=32, depth=2).to(DEV)
+    eager, graphed = MCTSAgent(net, n_nodes=16), MCTSAgent(net, n_nodes=16, graph=True)
+    graphed(worlds)                        # capture (consumes generator state during warm-up)
+    for move in range(4):
+        state = torch.cuda.get_rng_state()
+        a = eager(worlds)
+        torch.cuda.set_rng_state(state)
+        b = graphed(worlds)
+        for k in a:
+            assert torch.equal(a[k], b[k]), (move, k)
+        worlds, _ = worlds.step(a.actions)
