@@ -108,6 +108,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--envs', type=int, default=ENVS, help='envs per GPU (the metric is quoted at 4096)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--plain-network', action='store_true', help='run the nn.Module under autocast instead of the fp16 inference plan')
     ap.add_argument('--eager', action='store_true', help='launch kernel by kernel instead of replaying a HIP graph per move')
     args = ap.parse_args()
 
@@ -132,7 +133,7 @@ def main():
     net = networks.FCModel(worlds.obs_space, worlds.action_space, width=WIDTH, depth=DEPTH).cuda()
     worlds = premix(worlds, BOARD * BOARD // 3, gen)
     torch.manual_seed(1 + rank)
-    agent = MCTSAgent(net, n_nodes=NODES, graph=not args.eager)
+    agent = MCTSAgent(net if args.plain_network else networks.Inference(net), n_nodes=NODES, graph=not args.eager)
 
     timer = TimedExpand(lib)
     lib.bl_sim_expand = timer
@@ -171,7 +172,7 @@ def main():
         A, S = BOARD * BOARD, 2
         if not args.eager:
             # the same moves launched kernel by kernel, only to bracket every bl_sim_expand launch with HIP events
-            probe = MCTSAgent(net, n_nodes=NODES, graph=False)
+            probe = MCTSAgent(agent.network, n_nodes=NODES, graph=False)
             timer.on = True
             for _ in range(min(args.steps, 5)):
                 worlds, _ = worlds.step(probe(worlds).actions, check=False)

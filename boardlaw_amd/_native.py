@@ -18,7 +18,7 @@ class Search(ctypes.Structure):
     """bl_search_t"""
     _fields_ = [(k, _vp) for k in ('logits', 'v', 'w', 'n', 'children', 'parents', 'relation', 'rewards', 'terminal',
                                    'boards', 'seats', 'c_puct', 'qrange', 'exp_table')] + \
-               [('B', _i), ('T', _i), ('boardsize', _i)]
+               [('B', _i), ('T', _i), ('boardsize', _i), ('obs_f16', _i)]
 
 
 SYMBOLS = {
@@ -35,6 +35,8 @@ SYMBOLS = {
     'bl_sim_expand': (_i, [ctypes.POINTER(Search), _i] + [_vp] * 5 + [_vp]),
     'bl_sim_expand_counted': (_i, [ctypes.POINTER(Search), _i] + [_vp] * 6 + [_vp]),
     'bl_sim_backup': (_i, [ctypes.POINTER(Search), _i, _vp, _vp, _i, _vp, _i, _vp]),
+    'bl_sim_finish': (_i, [ctypes.POINTER(Search), _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    'bl_rezero_relu_f16': (_i, [_vp, _vp, _vp, _vp, _vp, ctypes.c_long, _vp]),
     'bl_sim_root': (_i, [ctypes.POINTER(Search), _i, _vp, _vp]),
     'bl_sim_init': (_i, [ctypes.POINTER(Search), _vp, _vp, _vp]),
 }

@@ -468,12 +468,12 @@ __global__ void __launch_bounds__(256) hex_observe_kernel(const uint8_t* board, 
 struct Search {
     uint16_t* logits; uint16_t* v; uint16_t* w; int16_t* n; int16_t* children; int16_t* parents; int16_t* relation;
     uint16_t* rewards; uint8_t* terminal; uint8_t* boards; int32_t* seats; const uint16_t* c_puct; uint32_t* qrange;
-    const float* exp_table; int B, T, S;
+    const float* exp_table; int B, T, S; int obs_f16;
 };
 
 template <int G, int K, bool COUNT>
 __global__ void __launch_bounds__(BL_WAVE) sim_expand_kernel(Search s, int sim, const uint16_t* rands, int16_t* leaves_out,
-                                                             float2* obs_out, uint8_t* valid_out, int32_t* leaf_seats_out,
+                                                             void* obs_out, uint8_t* valid_out, int32_t* leaf_seats_out,
                                                              unsigned long long* counters) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int S = s.S, A = S * S, T = s.T;
@@ -522,9 +522,9 @@ __global__ void __launch_bounds__(BL_WAVE) sim_expand_kernel(Search s, int sim, 
     for (int a = gl; a < A; a += G) {
         const int i = (int)(((float)a + 0.5f) * invS), j = a - i * S;
         const int color = term ? 2 : color_of(cells[flip ? j * S + i : a]);
-        float2 o = make_float2(0.f, 0.f);
-        if (color < 2) { if ((flip ? 1 - color : color) == 0) o.x = 1.f; else o.y = 1.f; }
-        obs_out[(long)b * A + a] = o;
+        const int ch = color < 2 ? (flip ? 1 - color : color) : 2;
+        if (s.obs_f16) ((uint32_t*)obs_out)[(long)b * A + a] = ch == 0 ? 0x00003c00u : (ch == 1 ? 0x3c000000u : 0u);   // f16 1.0 = 0x3c00
+        else ((float2*)obs_out)[(long)b * A + a] = make_float2(ch == 0 ? 1.f : 0.f, ch == 1 ? 1.f : 0.f);
         valid_out[(long)b * A + a] = color == 2;
     }
     if (gl == 0) {
@@ -568,6 +568,100 @@ __global__ void __launch_bounds__(BL_WAVE) sim_backup_kernel(Search s, int sim, 
         }
     }
     qrange_publish(s.qrange + 2 * BL_QSLOTS * (sim + 1), nmin, vmax, blockIdx.x % BL_QSLOTS);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// bl_sim_finish: the network's heads + mcts/__init__.py:135-140 in one launch, one wave per env.
+//   logits = log_softmax(masked_fill(policy_raw, ~valid, -inf)) in f32, stored as f16   (heads.py:101-104 under autocast,
+//            then decisions.logits.half()): the arithmetic follows torch's persistent-softmax kernel operation for
+//            operation (lane l holds elements l, l+W, ...; per-lane sequential exp-sum; xor-butterfly over W lanes;
+//            out = (x - max) - log(sum)), so the stored bits equal what F.log_softmax(...).half() gives on this device;
+//   v      = scatter_values(tanh(value_raw), seats) (heads.py:122-142): tanhf in f32, rounded to f16, negated for the
+//            other seat.
+// tests/test_gpu_parity.py::test_finish_heads_match_torch checks both against torch bit for bit.
+// ------------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(BL_WAVE) sim_finish_kernel(Search s, int sim, const int16_t* leaves, const uint16_t* policy_raw,
+                                                            const uint16_t* value_raw, const uint8_t* valid,
+                                                            const int32_t* leaf_seats, int W, int iters) {
+    const int S = s.S, A = S * S, T = s.T;
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const long envbase = (long)b * T;
+    const int leaf = leaves[b];
+    // ---- policy head
+    if (lane < W) {
+        float e[16];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int it = 0; it < 16; it++) {
+            e[it] = -INFINITY;
+            if (it < iters) {
+                const int a = lane + it * W;
+                if (a < A) e[it] = valid[(long)b * A + a] ? h2f(policy_raw[(long)b * A + a]) : -INFINITY;
+                mx = (it == 0) ? e[0] : ((mx > e[it]) ? mx : e[it]);
+            }
+        }
+        for (int off = W / 2; off > 0; off /= 2) { const float o = __shfl_xor(mx, off, W); mx = (mx < o) ? o : mx; }
+        float sum = 0.f;
+#pragma unroll
+        for (int it = 0; it < 16; it++) if (it < iters) sum += expf(e[it] - mx);
+        for (int off = W / 2; off > 0; off /= 2) sum = sum + __shfl_xor(sum, off, W);
+        const float lsum = logf(sum);
+        uint16_t* dst = s.logits + (envbase + leaf) * A;
+#pragma unroll
+        for (int it = 0; it < 16; it++) {
+            const int a = lane + it * W;
+            if (it < iters && a < A) dst[a] = f2h(e[it] - mx - lsum);
+        }
+    }
+    // ---- value head + backup walk, lanes 0 (seat 0) and 1 (seat 1)
+    if (lane < 2) {
+        const uint16_t tv = f2h(tanhf(h2f(value_raw[b])));
+        const int mover = leaf_seats[b];
+        const uint16_t vb = (lane == mover) ? tv : (uint16_t)(tv ^ 0x8000u);
+        s.v[(envbase + leaf) * 2 + lane] = vb;
+        backup_walk(s.rewards, s.parents, s.terminal, s.w, s.n, envbase, 2, lane, leaf, h2f(vb));
+    }
+    __syncthreads();   // workgroup-scope release/acquire: the walk's stores are visible to the scan below
+    uint32_t nmin = 0, vmax = 0;
+    for (int e = lane; e < T; e += BL_WAVE) {
+        const float den = (float)s.n[envbase + e] + 1.e-4f;
+        const uint32_t e0 = enc(h2f(s.w[(envbase + e) * 2]) / den), e1 = enc(h2f(s.w[(envbase + e) * 2 + 1]) / den);
+        nmin = max(nmin, max(~e0, ~e1)); vmax = max(vmax, max(e0, e1));
+    }
+    qrange_publish(s.qrange + 2 * BL_QSLOTS * (sim + 1), nmin, vmax, blockIdx.x % BL_QSLOTS);
+}
+
+// ReZero residual under fp16 autocast, fused (networks.py:17-18): x_out = x + alpha*y with torch's rounding points --
+// alpha (an f32 0-dim parameter) is cast to the tensors' dtype f16, the product is rounded to f16, the sum is rounded
+// to f16 -- plus relu(x_out) for the next block, 8 halves per thread.
+__global__ void __launch_bounds__(256) rezero_relu_kernel(const uint16_t* x, const uint16_t* y, const float* alpha,
+                                                         uint16_t* x_out, uint16_t* relu_out, long n8, long n) {
+    const float al = h2f(f2h(*alpha));
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long)gridDim.x * blockDim.x) {
+        const uint4 xv = ((const uint4*)x)[i], yv = ((const uint4*)y)[i];
+        const uint32_t xs[4] = {xv.x, xv.y, xv.z, xv.w}, ys[4] = {yv.x, yv.y, yv.z, yv.w};
+        uint32_t o[4], r[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            uint32_t ow = 0, rw = 0;
+#pragma unroll
+            for (int hlf = 0; hlf < 2; hlf++) {
+                const uint16_t xb = (uint16_t)(xs[j] >> (16 * hlf)), yb = (uint16_t)(ys[j] >> (16 * hlf));
+                const uint16_t ob = f2h(h2f(xb) + h2f(f2h(al * h2f(yb))));
+                const uint16_t rb = (ob & 0x8000u) ? (uint16_t)((ob & 0x7fffu) > 0x7c00u ? ob : 0) : ob;   // relu keeps NaN
+                ow |= (uint32_t)ob << (16 * hlf); rw |= (uint32_t)rb << (16 * hlf);
+            }
+            o[j] = ow; r[j] = rw;
+        }
+        ((uint4*)x_out)[i] = make_uint4(o[0], o[1], o[2], o[3]);
+        ((uint4*)relu_out)[i] = make_uint4(r[0], r[1], r[2], r[3]);
+    }
+    // tail (n not a multiple of 8)
+    for (long i = n8 * 8 + (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const uint16_t ob = f2h(h2f(x[i]) + h2f(f2h(al * h2f(y[i]))));
+        x_out[i] = ob;
+        relu_out[i] = (ob & 0x8000u) ? (uint16_t)((ob & 0x7fffu) > 0x7c00u ? ob : 0) : ob;
+    }
 }
 
 // Fills nbytes at p (16-B aligned, as torch allocations are) with a repeating 16-bit pattern; whole grid cooperates.
@@ -797,10 +891,10 @@ static int search_check(const bl_search_t* s) {
 static Search to_search(const bl_search_t* s) {
     return Search{(uint16_t*)s->logits, (uint16_t*)s->v, (uint16_t*)s->w, s->n, s->children, s->parents, s->relation,
                   (uint16_t*)s->rewards, s->terminal, s->boards, s->seats, (const uint16_t*)s->c_puct, s->qrange,
-                  s->exp_table, s->B, s->T, s->boardsize};
+                  s->exp_table, s->B, s->T, s->boardsize, s->obs_f16};
 }
 
-static int sim_expand_impl(const bl_search_t* s, int sim, const void* rands, int16_t* leaves, float* obs, uint8_t* valid,
+static int sim_expand_impl(const bl_search_t* s, int sim, const void* rands, int16_t* leaves, void* obs, uint8_t* valid,
                            int32_t* leaf_seats, unsigned long long* counters, bl_stream_t stream) {
     int rc = search_check(s);
     if (rc) return rc;
@@ -812,24 +906,24 @@ static int sim_expand_impl(const bl_search_t* s, int sim, const void* rands, int
     Search ss = to_search(s);
     if (counters) {
 #define CALL(g, k) hipLaunchKernelGGL((sim_expand_kernel<g, k, true>), dim3(blocks), dim3(64), (size_t)per * (64 / g), \
-                                      (hipStream_t)stream, ss, sim, (const uint16_t*)rands, leaves, (float2*)obs, valid, leaf_seats, counters)
+                                      (hipStream_t)stream, ss, sim, (const uint16_t*)rands, leaves, (void*)obs, valid, leaf_seats, counters)
         BL_DISPATCH_GK(G, K, CALL)
 #undef CALL
     } else {
 #define CALL(g, k) hipLaunchKernelGGL((sim_expand_kernel<g, k, false>), dim3(blocks), dim3(64), (size_t)per * (64 / g), \
-                                      (hipStream_t)stream, ss, sim, (const uint16_t*)rands, leaves, (float2*)obs, valid, leaf_seats, nullptr)
+                                      (hipStream_t)stream, ss, sim, (const uint16_t*)rands, leaves, (void*)obs, valid, leaf_seats, nullptr)
         BL_DISPATCH_GK(G, K, CALL)
 #undef CALL
     }
     return check_launch();
 }
 
-int bl_sim_expand(const bl_search_t* s, int sim, const void* rands, int16_t* leaves, float* obs, uint8_t* valid,
+int bl_sim_expand(const bl_search_t* s, int sim, const void* rands, int16_t* leaves, void* obs, uint8_t* valid,
                   int32_t* leaf_seats, bl_stream_t stream) {
     return sim_expand_impl(s, sim, rands, leaves, obs, valid, leaf_seats, nullptr, stream);
 }
 
-int bl_sim_expand_counted(const bl_search_t* s, int sim, const void* rands, int16_t* leaves, float* obs, uint8_t* valid,
+int bl_sim_expand_counted(const bl_search_t* s, int sim, const void* rands, int16_t* leaves, void* obs, uint8_t* valid,
                           int32_t* leaf_seats, unsigned long long* counters, bl_stream_t stream) {
     if (!counters) return BL_EINVAL;
     return sim_expand_impl(s, sim, rands, leaves, obs, valid, leaf_seats, counters, stream);
@@ -843,6 +937,30 @@ int bl_sim_backup(const bl_search_t* s, int sim, const int16_t* leaves, const vo
     const int blocks = (s->B + 3) / 4;
     hipLaunchKernelGGL(sim_backup_kernel, dim3(blocks), dim3(64), 0, (hipStream_t)stream, to_search(s), sim, leaves,
                        leaf_logits, logits_dtype, leaf_v, v_dtype);
+    return check_launch();
+}
+
+int bl_sim_finish(const bl_search_t* s, int sim, const int16_t* leaves, const void* policy_raw, const void* value_raw,
+                  const uint8_t* valid, const int32_t* leaf_seats, bl_stream_t stream) {
+    int rc = search_check(s);
+    if (rc) return rc;
+    if (!leaves || !policy_raw || !value_raw || !valid || !leaf_seats || sim < 1 || sim >= s->T) return BL_EINVAL;
+    const int A = s->boardsize * s->boardsize;
+    int np2 = 1; while (np2 < A) np2 *= 2;
+    const int W = np2 < 64 ? np2 : 64, iters = np2 / W;
+    if (iters > 16) return BL_ETOOBIG;
+    hipLaunchKernelGGL(sim_finish_kernel, dim3(s->B), dim3(64), 0, (hipStream_t)stream, to_search(s), sim, leaves,
+                       (const uint16_t*)policy_raw, (const uint16_t*)value_raw, valid, leaf_seats, W, iters);
+    return check_launch();
+}
+
+int bl_rezero_relu_f16(const void* x, const void* y, const float* alpha, void* x_out, void* relu_out, long n,
+                       bl_stream_t stream) {
+    if (!x || !y || !alpha || !x_out || !relu_out || n <= 0) return BL_EINVAL;
+    const long n8 = n / 8;
+    long blocks = (n8 + 255) / 256; if (blocks > 2048) blocks = 2048; if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(rezero_relu_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)x,
+                       (const uint16_t*)y, alpha, (uint16_t*)x_out, (uint16_t*)relu_out, n8, n);
     return check_launch();
 }
 

@@ -67,7 +67,7 @@ class LeafWorlds:
 class MCTS:
 
     def __init__(self, world, n_nodes=64, c_puct=1 / 16, noise_eps=.25, alpha_scale=10, fused=None, rng=None,
-                 count=False):
+                 count=False, obs_half=False):
         """c_puct high: concentrates on prior; c_puct low: concentrates on value (mcts/__init__.py:29-33)."""
         from .. import hex as hexmod
         self.device = world.device
@@ -100,7 +100,7 @@ class MCTS:
             self._qrange = e(T + 1, _native.QRANGE_WORDS, dtype=torch.int32)
             self._exp = _native.exp_table(dev)
             self._leaves = e(B, dtype=torch.short)
-            self._obs = e(B, bs, bs, 2, dtype=torch.float)
+            self._obs = e(B, bs, bs, 2, dtype=torch.half if obs_half else torch.float)
             self._valid = e(B, A, dtype=torch.bool)
             self._leaf_seats = e(B, dtype=torch.int)
             self.counters = torch.zeros(3 + 3 * B, dtype=torch.int64, device=dev) if count else None
@@ -110,7 +110,7 @@ class MCTS:
                 relation=self.tree.relation.data_ptr(), rewards=self.transitions.rewards.data_ptr(),
                 terminal=self.transitions.terminal.data_ptr(), boards=self.worlds.board.data_ptr(),
                 seats=self.worlds.seats.data_ptr(), c_puct=self.c_puct.data_ptr(), qrange=self._qrange.data_ptr(),
-                exp_table=self._exp.data_ptr(), B=B, T=T, boardsize=bs)
+                exp_table=self._exp.data_ptr(), B=B, T=T, boardsize=bs, obs_f16=int(obs_half))
             with torch.cuda.device(dev):
                 _native.check(_native.lib().bl_sim_init(ctypes.byref(self._search), world.board.contiguous().data_ptr(),
                                                         world.seats.int().contiguous().data_ptr(), _native.stream(dev)))
@@ -189,6 +189,16 @@ class MCTS:
                                                       self._obs.data_ptr(), self._valid.data_ptr(),
                                                       self._leaf_seats.data_ptr(), self.counters.data_ptr(), st))
             world = LeafWorlds(self, self._leaves, self._obs, self._valid, self._leaf_seats)
+            if hasattr(network, 'raw'):
+                # the network hands over its pre-head outputs; bl_sim_finish applies the heads, stores, backs up
+                with torch.no_grad(), torch.autocast('cuda', enabled=True):
+                    policy_raw, value_raw = network.raw(world)
+                policy_raw, value_raw = policy_raw.contiguous(), value_raw.contiguous()
+                assert policy_raw.dtype == torch.half and value_raw.dtype == torch.half
+                assert policy_raw.shape == (self.n_envs, self.n_actions) and value_raw.shape == (self.n_envs,)
+                _native.check(L.bl_sim_finish(s, self.sim, self._leaves.data_ptr(), policy_raw.data_ptr(), value_raw.data_ptr(),
+                                              self._valid.data_ptr(), self._leaf_seats.data_ptr(), st))
+                return
             with torch.no_grad(), torch.autocast('cuda', enabled=True):
                 decisions = network(world)
             logits, v = decisions.logits.contiguous(), decisions.v.contiguous()
@@ -233,7 +243,10 @@ class MCTS:
 
 
 def mcts(worlds, network, **kwargs):
+    kwargs.setdefault('obs_half', bool(getattr(network, 'wants_half_obs', False)))
     m = MCTS(worlds, **kwargs)
+    if hasattr(network, 'refresh'):
+        network.refresh()          # once per search: picks up optimiser steps, and is part of the captured move
     m.initialize(network)
     for _ in range(m.n_nodes - 1):
         m.simulate(network)

@@ -107,13 +107,15 @@ typedef struct {
     uint32_t* qrange;    /* (T+1, BL_QRANGE_WORDS) u32: row s is the state descend #s reads; bl_sim_init resets it */
     const float* exp_table;
     int B, T, boardsize;
+    int obs_f16;         /* 0: bl_sim_expand writes obs as f32 (the reference's layout); 1: as f16 (what fp16 autocast feeds
+                            the first Linear anyway; exact, the planes are 0/1) */
 } bl_search_t;
 
 /* mcts/__init__.py:113-129 + hex/__init__.py:148-195 for simulation number `sim` (1..T-1):
  * reads qrange slot `sim`, descends, creates/looks up the leaf, steps the parent's board, stores the leaf world and
  * its transition, and emits what the network needs for the leaf worlds. */
 int bl_sim_expand(const bl_search_t* s, int sim, const void* rands /*f16 (B,T)*/,
-                  int16_t* leaves_out /*(B)*/, float* obs_out /*(B,S,S,2) f32*/, uint8_t* valid_out /*(B,A)*/,
+                  int16_t* leaves_out /*(B)*/, void* obs_out /*(B,S,S,2) f32 or f16, see obs_f16*/, uint8_t* valid_out /*(B,A)*/,
                   int32_t* leaf_seats_out /*(B)*/, bl_stream_t stream);
 
 /* mcts/__init__.py:135-140: stores the network's outputs for the leaves (rounding to f16 exactly like `.half()`),
@@ -122,6 +124,18 @@ int bl_sim_expand(const bl_search_t* s, int sim, const void* rands /*f16 (B,T)*/
 int bl_sim_backup(const bl_search_t* s, int sim, const int16_t* leaves /*(B)*/,
                   const void* leaf_logits /*(B,A)*/, int logits_dtype, const void* leaf_v /*(B,2)*/, int v_dtype,
                   bl_stream_t stream);
+
+/* The same step when the network hands over its PRE-HEAD outputs: policy_raw (B,A) f16 = the policy Linear's output,
+ * value_raw (B) f16 = the value Linear's output (both under fp16 autocast).  Computes the heads of boardlaw/heads.py --
+ * masked log-softmax in f32 (heads.py:101-104) rounded to f16 like `.half()`, tanh + seat scatter (heads.py:122-142) --
+ * with torch's own operation order, then does what bl_sim_backup does. */
+int bl_sim_finish(const bl_search_t* s, int sim, const int16_t* leaves /*(B)*/, const void* policy_raw, const void* value_raw,
+                  const uint8_t* valid /*(B,A)*/, const int32_t* leaf_seats /*(B)*/, bl_stream_t stream);
+
+/* ReZero residual block tail under fp16 autocast (boardlaw/networks.py:17-18), fused: x_out = x + alpha*y (rounded
+ * where torch rounds) and relu_out = relu(x_out); n f16 elements, alpha one f32 on the device. */
+int bl_rezero_relu_f16(const void* x, const void* y, const float* alpha, void* x_out, void* relu_out, long n,
+                       bl_stream_t stream);
 
 /* root distribution from qrange slot `sim` (call with sim = number of filled slots, i.e. MCTS.sim). */
 int bl_sim_root(const bl_search_t* s, int sim, void* probs_out /*f16 (B,A)*/, bl_stream_t stream);
@@ -134,7 +148,7 @@ int bl_sim_init(const bl_search_t* s, const uint8_t* root_board /*(B,S,S)*/, con
 /* Diagnostics for the roofline model: bl_sim_expand plus counters accumulated into `counters`
  * ((3 + 3*B) x u64, device, caller-zeroed): [0] policy evaluations (d), [1] expanded-child lookups (k), [2] Newton
  * iterations; then per env {levels, Newton iterations, most iterations in one level}. */
-int bl_sim_expand_counted(const bl_search_t* s, int sim, const void* rands, int16_t* leaves_out, float* obs_out,
+int bl_sim_expand_counted(const bl_search_t* s, int sim, const void* rands, int16_t* leaves_out, void* obs_out,
                           uint8_t* valid_out, int32_t* leaf_seats_out, unsigned long long* counters,
                           bl_stream_t stream);
 

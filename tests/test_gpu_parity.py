@@ -344,3 +344,109 @@ def test_graphed_move_equals_eager_move():
         for k in a:
             assert torch.equal(a[k], b[k]), (move, k)
         worlds, _ = worlds.step(a.actions)
+
+
+def _expand_once(m, rands=None):
+    """Runs bl_sim_expand for the search's current sim and returns the leaf view (helper for the head tests)."""
+    import ctypes
+    from boardlaw_amd import _native
+    from boardlaw_amd.mcts import LeafWorlds
+    rands = torch.rand_like(m.decisions.logits[:, :, 0]) if rands is None else rands
+    _native.check(_native.lib().bl_sim_expand(ctypes.byref(m._search), m.sim, rands.data_ptr(), m._leaves.data_ptr(),
+                                              m._obs.data_ptr(), m._valid.data_ptr(), m._leaf_seats.data_ptr(), _native.stream()))
+    return LeafWorlds(m, m._leaves, m._obs, m._valid, m._leaf_seats)
+
+
+@pytest.mark.parametrize('S,B', [(3, 65536), (4, 1000), (5, 4096), (9, 4096), (11, 512), (13, 512), (19, 64)])
+def test_finish_heads_match_torch(S, B):
+    """bl_sim_finish's heads (masked log-softmax -> f16, tanh -> seat scatter) against torch's own ops on this device,
+    bit for bit: raw policy values over the whole f16 range of interest, every f16 value pattern for the value head
+    (S=3 case), ragged action counts on both sides of the 64-lane width."""
+    import ctypes
+    from boardlaw_amd import _native, heads
+    from boardlaw_amd.hex import Hex
+    from boardlaw_amd.mcts import MCTS
+    torch.manual_seed(S)
+    A = S * S
+    worlds = Hex.initial(B, S, device=DEV)
+    for _ in range(A // 3):
+        v = worlds.valid
+        worlds, _ = worlds.step((torch.rand(v.shape, device=DEV) * v).argmax(-1), check=False)
+    m = MCTS(worlds, n_nodes=4, noise_eps=0.)
+    m.plant_root(torch.log_softmax(torch.randn(B, A, device=DEV).masked_fill(~worlds.valid, -np.inf), -1), torch.zeros(B, 2, device=DEV))
+    leaf = _expand_once(m)
+    policy_raw = (torch.randn(B, A, device=DEV) * 4).half()
+    policy_raw[::7] *= 8
+    if B == 65536:
+        value_raw = torch.arange(65536, dtype=torch.int32, device=DEV).to(torch.int16).view(torch.half)
+    else:
+        value_raw = (torch.randn(B, device=DEV) * 2).half()
+    _native.check(_native.lib().bl_sim_finish(ctypes.byref(m._search), m.sim, m._leaves.data_ptr(), policy_raw.data_ptr(),
+                                              value_raw.data_ptr(), m._valid.data_ptr(), m._leaf_seats.data_ptr(), _native.stream()))
+    with torch.autocast('cuda'):
+        want_logits = torch.nn.functional.log_softmax(policy_raw.masked_fill(~leaf.valid, -np.inf), -1).half()
+        want_v = heads.scatter_values(torch.tanh(value_raw), leaf.seats).half()
+    got_logits = m.decisions.logits[m.envs, m._leaves.long()]
+    got_v = m.decisions.v[m.envs, m._leaves.long()]
+    assert np.array_equal(bits16(got_logits), bits16(want_logits))
+    nan = torch.isnan(want_v)
+    assert torch.equal(torch.isnan(got_v), nan)
+    assert np.array_equal(bits16(got_v)[~nan.cpu().numpy()], bits16(want_v)[~nan.cpu().numpy()])
+
+
+def test_inference_plan_matches_autocast():
+    """networks.Inference.raw (cached f16 weights + fused ReZero kernel) == FCModel.raw under fp16 autocast, bitwise."""
+    from boardlaw_amd import networks, heads
+    torch.manual_seed(5)
+    for (S, width, depth, B) in [(9, 512, 4, 4096), (5, 16, 4, 64), (13, 256, 2, 1000)]:
+        net = networks.FCModel(heads.Tensor((S, S, 2)), heads.Masked(S * S), width=width, depth=depth).to(DEV)
+        with torch.no_grad():
+            for blk in list(net.body)[1:]:
+                getattr(blk, 'α').fill_(float(torch.randn(()) * 0.37))      # not f16-representable
+        class W: pass
+        w = W()
+        w.obs = (torch.rand(B, S, S, 2, device=DEV) < .3).float()
+        inf = networks.Inference(net)
+        with torch.no_grad(), torch.autocast('cuda'):
+            p0, v0 = net.raw(w)
+            p1, v1 = inf.raw(w)
+            w.obs = w.obs.half()
+            p2, v2 = inf.raw(w)
+        assert p0.dtype == torch.half and torch.equal(p0, p1) and torch.equal(v0, v1)
+        assert torch.equal(p0, p2) and torch.equal(v0, v2)
+        # a training step must be picked up by refresh()
+        with torch.no_grad():
+            net.policy.core.bias.add_(1.)
+        inf.refresh()
+        with torch.no_grad(), torch.autocast('cuda'):
+            assert torch.equal(net.raw(w)[0], inf.raw(w)[0])
+
+
+def test_raw_path_equals_torch_heads_path():
+    """A whole search with the network's heads applied by bl_sim_finish equals the search with torch's heads feeding
+    bl_sim_backup (same draws): trees, visit counts, root distribution."""
+    from boardlaw_amd import hex, networks
+    from boardlaw_amd.mcts import MCTS
+    torch.manual_seed(1)
+    worlds = hex.Hex.initial(512, 7, device=DEV)
+    net = networks.FCModel(worlds.obs_space, worlds.action_space, width=64, depth=3).to(DEV)
+    with torch.no_grad():
+        for blk in list(net.body)[1:]:
+            getattr(blk, 'α').fill_(.3)
+    class HeadsOnly:                      # hides .raw so that the search takes the torch-heads path
+        def __init__(self, n): self.n = n
+        def __call__(self, w): return self.n(w)
+    results = []
+    for network in (net, HeadsOnly(net), networks.Inference(net)):
+        torch.manual_seed(2)
+        m = MCTS(worlds, n_nodes=24, obs_half=bool(getattr(network, 'wants_half_obs', False)))
+        m.initialize(network)
+        for _ in range(23):
+            m.simulate(network)
+        results.append(m)
+    for other in results[1:]:
+        for a, b in [(results[0].tree.children, other.tree.children), (results[0].stats.n, other.stats.n),
+                     (results[0].stats.w, other.stats.w), (results[0].decisions.logits, other.decisions.logits),
+                     (results[0].decisions.v, other.decisions.v)]:
+            assert np.array_equal(to_np(a), to_np(b))
+        assert torch.equal(results[0].root_probs(), other.root_probs())
