@@ -72,9 +72,9 @@ def tree_statistics(worlds, net, nodes):
     m.initialize(net)
     for _ in range(nodes - 1):
         m.simulate(net)
-    c = m.counters.cpu().numpy().astype(np.float64)
+    c = m.counters.cpu().numpy().astype(np.float64).sum(0)
     descents = worlds.n_envs * (nodes - 1)
-    return c[0] / descents, c[1] / descents, c[2] / max(c[0], 1)
+    return c[0] / descents, c[3] / descents, c[1] / max(c[0], 1)
 
 
 def expand_bytes_per_env(A, S, d, k):

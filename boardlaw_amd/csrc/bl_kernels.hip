@@ -135,6 +135,8 @@ __device__ __forceinline__ int policy_eval(const Tree& m, int b, int t, int seat
     int Nloc = 0, nch = 0;
     const long envbase = (long)b * T;
     const long row = (envbase + t) * A;
+    long long tp0 = 0, tdiv = 0, tfold = 0, tupd = 0;     // phase clocks, COUNT builds only
+    if (COUNT) tp0 = clock64();
     // round trip 1: the node's two rows, coalesced across the group
 #pragma unroll
     for (int k = 0; k < K; k++) {
@@ -174,11 +176,15 @@ __device__ __forceinline__ int policy_eval(const Tree& m, int b, int t, int seat
         if (k * G + gl < A) alpha = fmaxf(alpha, q[k] + fmaxf(top[k], 1.e-4f));
     }
     alpha = gmaxf<G>(alpha);
+    long long tload = 0;
+    if (COUNT) { tload = clock64() - tp0; }
 
     float err = INFINITY;
     bool conv = !go;      // group-uniform
     int iters = 0;
     for (int it = 0; it < 101; it++) {
+        long long ti0 = 0;
+        if (COUNT) ti0 = clock64();
         // iteration 100 only happens for groups that ran out of Newton steps: their alpha moved after the last fold
         // (cuda.cu:48-65), so the probabilities are evaluated once more at the final alpha for the draw.
         if (!__any(!conv)) break;
@@ -195,9 +201,13 @@ __device__ __forceinline__ int policy_eval(const Tree& m, int b, int t, int seat
             }
         }
         __syncthreads();
+        long long ti1 = 0;
+        if (COUNT) { ti1 = clock64(); tdiv += ti1 - ti0; }
         float acc = 0.f;
         if (!conv && gl < 2) acc = serial_prefix(gl == 0 ? L.s : L.g, A);
         const float Ssum = __shfl(acc, 0, G), gsum_ = __shfl(acc, 1, G);
+        long long ti2 = 0;
+        if (COUNT) { ti2 = clock64(); tfold += ti2 - ti1; }
         if (!conv) {
             if (it == 100) { conv = true; }
             else {
@@ -208,6 +218,7 @@ __device__ __forceinline__ int policy_eval(const Tree& m, int b, int t, int seat
             }
         }
         __syncthreads();
+        if (COUNT) tupd += clock64() - ti2;
     }
     // The draw, cuda.cu:157-176: first a (ascending) with prob > 0 and running total >= r, else the last a with prob > 0.
     // L.s now holds the running totals in the reference's summation order; every lane tests its own actions.
@@ -227,17 +238,226 @@ __device__ __forceinline__ int policy_eval(const Tree& m, int b, int t, int seat
         last = max(last, __shfl_xor(last, msk, G));
     }
     if (COUNT && go) {
+        // diagnostics, per env, plain stores (atomics would perturb the memory timings being measured):
+        // {levels, Newton iterations, most iterations in a level, child look-ups, clocks: loads, terms, folds, update}
         const int nc = gsum<G>(nch);
         if (gl == 0) {
-            atomicAdd(&counters[0], 1ull);
-            atomicAdd(&counters[1], (unsigned long long)nc);
-            atomicAdd(&counters[2], (unsigned long long)iters);
-            // per-env totals for this launch: levels, Newton iterations, worst level
-            unsigned long long* e = counters + 3 + 3 * (long)b;
-            e[0] += 1; e[1] += iters; if ((unsigned long long)iters > e[2]) e[2] = iters;
+            unsigned long long* e = counters + 12 * (long)b;
+            e[0] += 1; e[1] += iters; if ((unsigned long long)iters > e[2]) e[2] = iters; e[3] += nc;
+            e[4] += tload; e[5] += tdiv; e[6] += tfold; e[7] += tupd;
         }
     }
     return first != 0x7fffffff ? first : last;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// One-wave-per-env (G == 64) specialisation of policy_eval: no LDS, no barriers.
+//
+// The serial fold runs across LANES with DPP: after  x <- t  and  x[lane 0] <- carry + t[0],  the step
+//     x[i] <- x[i-1] + t[i]   for every lane i >= 1 at once     (v_add_f32_dpp ... wave_shr:1, lane 0 keeps its value)
+// applied j times makes lanes 0..j hold the reference's running total  ((carry + t0) + t1) + ...  exactly -- each
+// lane's last update reads a neighbour that is already final, and later updates recompute the same sum.  63 steps
+// finish a 64-action register; the totals stay in registers, which is what the draw needs.  S and g chains interleave,
+// filling each other's DPP wait states.
+// ------------------------------------------------------------------------------------------------------------------
+template <int CTRL, int RM>
+__device__ __forceinline__ int dpp_i(int old, int v) { return __builtin_amdgcn_update_dpp(old, v, CTRL, RM, 0xf, false); }
+template <int CTRL, int RM>
+__device__ __forceinline__ float dpp_f(float old, float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, v), CTRL, RM, 0xf, false));
+}
+__device__ __forceinline__ int wave_sum_i32(int v) {     // integer: any order is exact
+    v += dpp_i<0x111, 0xf>(0, v); v += dpp_i<0x112, 0xf>(0, v); v += dpp_i<0x114, 0xf>(0, v); v += dpp_i<0x118, 0xf>(0, v);
+    v += dpp_i<0x142, 0xa>(0, v); v += dpp_i<0x143, 0xc>(0, v);
+    return __builtin_amdgcn_readlane(v, 63);
+}
+__device__ __forceinline__ float wave_max_f32(float v) {   // max: any order is exact
+    v = fmaxf(v, dpp_f<0x111, 0xf>(v, v)); v = fmaxf(v, dpp_f<0x112, 0xf>(v, v)); v = fmaxf(v, dpp_f<0x114, 0xf>(v, v));
+    v = fmaxf(v, dpp_f<0x118, 0xf>(v, v)); v = fmaxf(v, dpp_f<0x142, 0xa>(v, v)); v = fmaxf(v, dpp_f<0x143, 0xc>(v, v));
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+__device__ __forceinline__ float readlane_f(float v, int lane) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
+}
+
+// One step of both chains.  The ISA asks for 2 wait states between a VALU write and a DPP read of the same VGPR; each
+// chain's next step is separated from its previous one by the other chain's instruction.  tools/micro/dpp_hazard.hip
+// measures that this one intervening VALU instruction is sufficient on gfx950 (0 wrong lanes in 2e8; back-to-back
+// steps of ONE chain do fail), and the in-order VALU pipeline makes that timing independent of other waves; an extra
+// s_nop per step costs 35 % of the fold.
+#define BL_FOLD_STEP "v_add_f32_dpp %0, %0, %2 wave_shr:1 row_mask:0xf bank_mask:0xf\n\tv_add_f32_dpp %1, %1, %3 wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+// 8 fold steps of both chains.  The leading s_nop covers the VALU-write -> DPP-read hazard against whatever wrote x/y.
+#define BL_FOLD8(x, y, ts, tg)                                                                              \
+    asm volatile("s_nop 1\n\t" BL_FOLD_STEP BL_FOLD_STEP BL_FOLD_STEP BL_FOLD_STEP BL_FOLD_STEP BL_FOLD_STEP \
+                 BL_FOLD_STEP BL_FOLD_STEP : "+v"(x), "+v"(y) : "v"(ts), "v"(tg))
+
+template <int K, bool COUNT, bool WANT_PROB>
+__device__ __forceinline__ int policy_eval_wave(const Tree& m, int b, int t, int seat, float lo, float rden, float r,
+                                                const GroupLds& L, float (&prob)[K], int& next_child, int& next_info,
+                                                unsigned long long* counters) {
+    const int A = m.A, T = m.T, S = m.S;
+    const int lane = threadIdx.x & 63;
+    float top[K], q[K], tg[K];
+    int child[K], info[K];
+    uint16_t lb[K];
+    int Nloc = 0, nch = 0;
+    const long envbase = (long)b * T;
+    const long row = (envbase + t) * A;
+    long long tp0 = 0, tdiv = 0, tfold = 0, tupd = 0;
+    if (COUNT) tp0 = clock64();
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+        const int a = k * 64 + lane;
+        child[k] = -1; lb[k] = 0; info[k] = 0;
+        if (a < A) { child[k] = m.children[row + a]; lb[k] = m.logits[row + a]; }
+    }
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+        const int a = k * 64 + lane;
+        float pi = 0.f, qa = 0.f;
+        if (a < A) {
+            pi = m.exp_table[lb[k]];
+            if (child[k] > -1) {
+                const long i = envbase + child[k];
+                const float wv = h2f(m.w[i * S + seat]);
+                const int nv = m.n[i];
+                info[k] = (m.terminal[i] ? 1 : 0) | (load_seat(m, i) << 1);
+                const float q32 = wv / ((float)nv + 1.e-4f);
+                qa = h2f(f2h((q32 - lo) / rden));
+                Nloc += nv;
+                nch++;
+            } else {
+                Nloc += 1;
+            }
+        }
+        top[k] = pi; q[k] = qa; prob[k] = 0.f; tg[k] = 0.f;
+    }
+    const int N = wave_sum_i32(Nloc);
+    const float lam = (h2f(m.c_puct[b]) * (float)N) / (float)(unsigned)(N + A);
+    float alpha = 0.f;
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+        top[k] = lam * top[k];
+        if (k * 64 + lane < A) alpha = fmaxf(alpha, q[k] + fmaxf(top[k], 1.e-4f));
+    }
+    alpha = wave_max_f32(alpha);
+
+    // Compact the actions whose terms are not identically zero (top != 0) to the front, keeping their order.  A term
+    // with top == 0 (an illegal move: logit -inf) contributes s = +0 and g = -0 to the folds, and x + (+-0) == x for
+    // every partial sum the folds can hold, so dropping those steps leaves every rounding unchanged -- and a mid-game
+    // board's legal moves usually fit one 64-lane register, halving the divisions and shortening the serial chain.
+    float ctop[K], cq[K];
+    int ca[K];
+    int n_c = 0;
+    {
+        int rank[K];
+#pragma unroll
+        for (int k = 0; k < K; k++) {
+            const bool present = (k * 64 + lane < A) && (top[k] != 0.f);
+            const unsigned long long mk = __ballot(present);
+            rank[k] = present ? n_c + __builtin_popcountll(mk & ((1ull << lane) - 1ull)) : -1;
+            n_c += __builtin_popcountll(mk);
+        }
+#pragma unroll
+        for (int k = 0; k < K; k++) if (rank[k] >= 0) { L.s[rank[k]] = top[k]; L.g[rank[k]] = q[k]; L.child[rank[k]] = (int16_t)(k * 64 + lane); }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < K; k++) {
+            const int j = k * 64 + lane;
+            const bool in = j < n_c;
+            ctop[k] = in ? L.s[j] : 0.f; cq[k] = in ? L.g[j] : 0.f; ca[k] = in ? (int)L.child[j] : -1;
+        }
+        __syncthreads();
+    }
+    long long tload = 0;
+    if (COUNT) tload = clock64() - tp0;
+
+    float err = INFINITY;
+    int iters = 0;
+    float tot[K], cprob[K];
+#pragma unroll
+    for (int k = 0; k < K; k++) { tot[k] = 0.f; cprob[k] = 0.f; }
+    const int last_k = (n_c - 1) >> 6, last_lane = (n_c - 1) & 63;
+    for (int it = 0; it < 101 && n_c > 0; it++) {
+        long long ti0 = 0, ti1 = 0, ti2 = 0;
+        if (COUNT) ti0 = clock64();
+#pragma unroll
+        for (int k = 0; k < K; k++) {
+            if (k <= last_k) {
+                const float bot = alpha - cq[k];
+                const bool in = k * 64 + lane < n_c;
+                cprob[k] = in ? ctop[k] / bot : 0.f;        // lanes past the end fold +0: harmless to every earlier lane
+                tg[k] = in ? (-ctop[k]) / (bot * bot) : 0.f;
+            }
+        }
+        if (COUNT) { ti1 = clock64(); tdiv += ti1 - ti0; }
+        float cs = 0.f, cg = 0.f, Ssum = 0.f, gsum_ = 0.f;
+#pragma unroll
+        for (int k = 0; k < K; k++) {
+            if (k <= last_k) {
+                float x = cprob[k], y = tg[k];
+                if (lane == 0) { x = cs + x; y = cg + y; }
+                const int steps = (k == last_k) ? last_lane : 63;
+                for (int j = 0; j < steps; j += 8) BL_FOLD8(x, y, cprob[k], tg[k]);
+                tot[k] = x;
+                if (k == last_k) { Ssum = readlane_f(x, last_lane); gsum_ = readlane_f(y, last_lane); }
+                else { cs = readlane_f(x, 63); cg = readlane_f(y, 63); }
+            }
+        }
+        if (COUNT) { ti2 = clock64(); tfold += ti2 - ti1; }
+        if (it == 100) break;     // alpha had moved after the 100th fold (cuda.cu:48-65): this pass only refreshed prob/tot
+        iters++;
+        const float ne = Ssum - 1.f;
+        if ((ne < 1e-3f) || (err == ne)) break;
+        alpha -= ne / gsum_; err = ne;
+        if (COUNT) tupd += clock64() - ti2;
+    }
+    // The draw, cuda.cu:157-176, on the running totals each lane holds for its own (compacted) actions: the first with
+    // prob > 0 and total >= r, else the last with prob > 0.  Dropped actions have prob == 0 and can never be drawn.
+    int action = -1, lastpos = -1;
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+        if (k <= last_k) {
+            const bool pos = (k * 64 + lane < n_c) && cprob[k] > 0.f;
+            const unsigned long long hit = __ballot(pos && tot[k] >= r), anyp = __ballot(pos);
+            if (action < 0 && hit) action = __builtin_amdgcn_readlane(ca[k], __builtin_ctzll(hit));
+            if (anyp) lastpos = __builtin_amdgcn_readlane(ca[k], 63 - __builtin_clzll(anyp));
+        }
+    }
+    if (action < 0) action = lastpos;
+    next_child = -1; next_info = 0;
+    if (action >= 0) {
+#pragma unroll
+        for (int k = 0; k < K; k++) if ((action >> 6) == k) {
+            next_child = __builtin_amdgcn_readlane(child[k], action & 63);
+            next_info = __builtin_amdgcn_readlane(info[k], action & 63);
+        }
+    }
+    if (WANT_PROB) {
+        // un-compact prob(a) for the caller (root read-out): every action reads its compacted slot back
+        int rank2 = 0;
+#pragma unroll
+        for (int k = 0; k < K; k++) { const int j = k * 64 + lane; if (j < n_c) L.s[j] = cprob[k]; }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < K; k++) {
+            const bool present = (k * 64 + lane < A) && (top[k] != 0.f);
+            const unsigned long long mk = __ballot(present);
+            prob[k] = present ? L.s[rank2 + __builtin_popcountll(mk & ((1ull << lane) - 1ull))] : 0.f;
+            rank2 += __builtin_popcountll(mk);
+        }
+        // an action whose top is 0 has prob 0/(alpha-q) = +0 unless alpha == q (0/0 = NaN in the reference);
+        // alpha >= q + 1e-4 always (cuda.cu:37-41), so +0 it is.
+    }
+    if (COUNT) {
+        const int nc = wave_sum_i32(nch);
+        if (lane == 0) {
+            unsigned long long* e = counters + 12 * (long)b;
+            e[0] += 1; e[1] += iters; if ((unsigned long long)iters > e[2]) e[2] = iters; e[3] += nc;
+            e[4] += tload; e[5] += tdiv; e[6] += tfold; e[7] += tupd;
+        }
+    }
+    return action;
 }
 
 // descend_kernel's per-env loop, cuda.cu:138-182.  Returns group-uniform (parent, action, next) where next ==
@@ -261,19 +481,28 @@ __device__ __forceinline__ void descend_group(const Tree& m, int b, bool act, in
         if (!__any(go)) break;
         const float r = go ? h2f(rands[envbase + t]) : 0.f;
         float prob[K];
-        const int a = policy_eval<G, K, COUNT>(m, b, t, seat, go, gl, lo, rden, r, L, prob, counters);
-        if (go) {
-            action = a;
+        if constexpr (G == 64) {
+            // one env per wave: `go` is wave-uniform, the whole wave is here
+            int nchild, ninfo;
+            action = policy_eval_wave<K, COUNT, false>(m, b, t, seat, lo, rden, r, L, prob, nchild, ninfo, counters);
             parent = t;
-            if (action < 0) { act = false; }   // reference would index children[b][t][-1]; unreachable with a finite logit
-            else {
-                t = L.child[action];
-                const int info = L.info[action];
-                term = (t != -1) && (info & 1);
-                seat = info >> 1;
+            if (action < 0) { act = false; }
+            else { t = nchild; term = (t != -1) && (ninfo & 1); seat = ninfo >> 1; }
+        } else {
+            const int a = policy_eval<G, K, COUNT>(m, b, t, seat, go, gl, lo, rden, r, L, prob, counters);
+            if (go) {
+                action = a;
+                parent = t;
+                if (action < 0) { act = false; }   // reference would index children[b][t][-1]; unreachable with a finite logit
+                else {
+                    t = L.child[action];
+                    const int info = L.info[action];
+                    term = (t != -1) && (info & 1);
+                    seat = info >> 1;
+                }
             }
+            __syncthreads();
         }
-        __syncthreads();
     }
     parent_out = parent; action_out = action; next_out = t;
 }
@@ -302,7 +531,12 @@ __global__ void __launch_bounds__(BL_WAVE) root_kernel(Tree m, uint16_t* probs) 
     const bool go = b < m.B;
     const int seat = go ? load_seat(m, (long)b * m.T) : 0;
     float prob[K];
-    policy_eval<G, K, false>(m, b, 0, seat, go, gl, lo, hi - lo + 1.e-4f, 2.f, L, prob, nullptr);
+    if constexpr (G == 64) {
+        int c, i;
+        if (go) policy_eval_wave<K, false, true>(m, b, 0, seat, lo, hi - lo + 1.e-4f, 2.f, L, prob, c, i, nullptr);
+    } else {
+        policy_eval<G, K, false>(m, b, 0, seat, go, gl, lo, hi - lo + 1.e-4f, 2.f, L, prob, nullptr);
+    }
     if (go) {
 #pragma unroll
         for (int k = 0; k < K; k++) {
@@ -488,9 +722,12 @@ __global__ void __launch_bounds__(BL_WAVE) sim_expand_kernel(Search s, int sim, 
     m.children = s.children; m.qrange = s.qrange + 2 * BL_QSLOTS * sim; m.exp_table = s.exp_table;
     m.B = s.B; m.T = T; m.A = A; m.S = 2; m.seats_i32 = 1;
 
+    long long tk0 = 0, tk1 = 0;
+    if (COUNT) tk0 = clock64();
     int parent, action, nxt;
     descend_group<G, K, COUNT>(m, b, act, gl, rands, L, counters, parent, action, nxt);
     if (action < 0) action = 0;
+    if (COUNT) tk1 = clock64();
 
     // leaves = children[envs, parents, actions]; leaves[leaves == -1] = sim   (mcts/__init__.py:117-122)
     const int leaf = (nxt == -1) ? sim : nxt;
@@ -535,6 +772,12 @@ __global__ void __launch_bounds__(BL_WAVE) sim_expand_kernel(Search s, int sim, 
         s.rewards[(envbase + leaf) * 2 + 1] = f2h((float)(-win));
         leaves_out[b] = (int16_t)leaf;
         leaf_seats_out[b] = new_seat;
+    }
+    if (COUNT && gl == 0) {
+        unsigned long long* e = counters + 12 * (long)b;
+        const long long tk2 = clock64();
+        e[8] += tk1 - tk0;    // descent, all levels
+        e[9] += tk2 - tk1;    // expansion: step + flood + observe + stores
     }
 }
 

@@ -103,7 +103,7 @@ class MCTS:
             self._obs = e(B, bs, bs, 2, dtype=torch.half if obs_half else torch.float)
             self._valid = e(B, A, dtype=torch.bool)
             self._leaf_seats = e(B, dtype=torch.int)
-            self.counters = torch.zeros(3 + 3 * B, dtype=torch.int64, device=dev) if count else None
+            self.counters = torch.zeros((B, 12), dtype=torch.int64, device=dev) if count else None
             self._search = _native.Search(
                 logits=self.decisions.logits.data_ptr(), v=self.decisions.v.data_ptr(), w=self.stats.w.data_ptr(),
                 n=self.stats.n.data_ptr(), children=self.tree.children.data_ptr(), parents=self.tree.parents.data_ptr(),

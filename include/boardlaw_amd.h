@@ -145,9 +145,10 @@ int bl_sim_root(const bl_search_t* s, int sim, void* probs_out /*f16 (B,A)*/, bl
 int bl_sim_init(const bl_search_t* s, const uint8_t* root_board /*(B,S,S)*/, const int32_t* root_seats /*(B)*/,
                 bl_stream_t stream);
 
-/* Diagnostics for the roofline model: bl_sim_expand plus counters accumulated into `counters`
- * ((3 + 3*B) x u64, device, caller-zeroed): [0] policy evaluations (d), [1] expanded-child lookups (k), [2] Newton
- * iterations; then per env {levels, Newton iterations, most iterations in one level}. */
+/* Diagnostics for the roofline model: bl_sim_expand that also accumulates, per env, into `counters`
+ * ((B,12) u64, device, caller-zeroed): [0] policy evaluations (levels), [1] Newton iterations, [2] most iterations in
+ * one level, [3] expanded-child look-ups, then shader-clock totals [4] loads, [5] term evaluation, [6] serial folds,
+ * [7] alpha update, [8] whole descent, [9] expansion (step+flood+observe+stores); [10..11] unused. */
 int bl_sim_expand_counted(const bl_search_t* s, int sim, const void* rands, int16_t* leaves_out, void* obs_out,
                           uint8_t* valid_out, int32_t* leaf_seats_out, unsigned long long* counters,
                           bl_stream_t stream);

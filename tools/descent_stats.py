@@ -1,4 +1,4 @@
-"""Distribution of per-env descent work (levels, Newton iterations) across a search: explains the kernel's tail."""
+"""Distribution of per-env descent work and where a wave's cycles go (counting build of bl_sim_expand)."""
 import os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -15,8 +15,11 @@ m.initialize(net)
 for sim in range(1, 64):
     m.counters.zero_()
     m.simulate(net)
-    if sim in (2, 8, 16, 32, 48, 63):
-        c = m.counters.cpu().numpy()
-        per = c[3:].reshape(-1, 3)
-        lv, it, mx = per[:, 0], per[:, 1], per[:, 2]
-        print(f'sim {sim:2d}: levels mean {lv.mean():.2f} max {lv.max()} p99 {np.percentile(lv,99):.0f} | iters/env mean {it.mean():.1f} max {it.max()} p99 {np.percentile(it,99):.0f} | worst level iters max {mx.max()} p99 {np.percentile(mx,99):.0f} (#envs with a level >=20 its: {(mx>=20).sum()}, ==100: {(mx>=100).sum()})')
+    if sim in (2, 16, 32, 63):
+        c = m.counters.cpu().numpy().astype(np.float64)
+        lv, it = c[:, 0], c[:, 1]
+        worst = int(np.argmax(c[:, 8] + c[:, 9]))
+        def row(x): return f'levels {x[0]:.1f} iters {x[1]:.1f} | cycles: loads {x[4]:.0f} terms {x[5]:.0f} folds {x[6]:.0f} update {x[7]:.0f} | descent {x[8]:.0f} expansion {x[9]:.0f}'
+        print(f'sim {sim:2d}: levels max {lv.max():.0f} p99 {np.percentile(lv,99):.0f}; iters max {it.max():.0f}')
+        print('   mean env :', row(c.mean(0)))
+        print('   worst env:', row(c[worst]))
