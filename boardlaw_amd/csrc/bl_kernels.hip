@@ -276,6 +276,12 @@ __device__ __forceinline__ float wave_max_f32(float v) {   // max: any order is 
     v = fmaxf(v, dpp_f<0x118, 0xf>(v, v)); v = fmaxf(v, dpp_f<0x142, 0xa>(v, v)); v = fmaxf(v, dpp_f<0x143, 0xc>(v, v));
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
+    v = max(v, (uint32_t)dpp_i<0x111, 0xf>(0, (int)v)); v = max(v, (uint32_t)dpp_i<0x112, 0xf>(0, (int)v));
+    v = max(v, (uint32_t)dpp_i<0x114, 0xf>(0, (int)v)); v = max(v, (uint32_t)dpp_i<0x118, 0xf>(0, (int)v));
+    v = max(v, (uint32_t)dpp_i<0x142, 0xa>(0, (int)v)); v = max(v, (uint32_t)dpp_i<0x143, 0xc>(0, (int)v));
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
 __device__ __forceinline__ float readlane_f(float v, int lane) {
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
 }
@@ -464,8 +470,8 @@ __device__ __forceinline__ int policy_eval_wave(const Tree& m, int b, int t, int
 // children[b,parent,action] (-1 for an unexpanded edge, a terminal node's id otherwise).
 template <int G, int K, bool COUNT>
 __device__ __forceinline__ void descend_group(const Tree& m, int b, bool act, int gl, const uint16_t* rands,
-                                              const GroupLds& L, unsigned long long* counters,
-                                              int& parent_out, int& action_out, int& next_out) {
+                                              const GroupLds& L, unsigned long long* counters, int16_t* path,
+                                              int& parent_out, int& action_out, int& next_out, int& depth_out) {
     float lo, hi;
     load_qrange(m.qrange, lo, hi);
     const float rden = hi - lo + 1.e-4f;
@@ -476,10 +482,16 @@ __device__ __forceinline__ void descend_group(const Tree& m, int b, bool act, in
     if (act) { term = m.terminal[envbase]; seat = load_seat(m, envbase); }
     // A root-to-leaf path in a T-slot tree has at most T nodes; the bound only matters for a corrupted tree, where the
     // reference's while(true) (cuda.cu:149) would spin forever.
+    int nlevels = 0;
     for (int depth = 0; depth < m.T; depth++) {
         const bool go = act && (t != -1) && !term;
         if (!__any(go)) break;
         const float r = go ? h2f(rands[envbase + t]) : 0.f;
+        if (go) {
+            // the visited nodes, root first: bl_sim_finish walks them without chasing parents[]
+            if (path && gl == 0) path[1 + depth] = (int16_t)t;
+            nlevels = depth + 1;
+        }
         float prob[K];
         if constexpr (G == 64) {
             // one env per wave: `go` is wave-uniform, the whole wave is here
@@ -504,7 +516,7 @@ __device__ __forceinline__ void descend_group(const Tree& m, int b, bool act, in
             __syncthreads();
         }
     }
-    parent_out = parent; action_out = action; next_out = t;
+    parent_out = parent; action_out = action; next_out = t; depth_out = nlevels;
 }
 
 template <int G, int K, bool COUNT>
@@ -514,8 +526,8 @@ __global__ void __launch_bounds__(BL_WAVE) descend_kernel(Tree m, const uint16_t
     const int grp = threadIdx.x / G, gl = threadIdx.x % G;
     const int b = blockIdx.x * (BL_WAVE / G) + grp;
     const GroupLds L(smem + (size_t)grp * lds_bytes(m.A, false), m.A);
-    int parent, action, nxt;
-    descend_group<G, K, COUNT>(m, b, b < m.B, gl, rands, L, counters, parent, action, nxt);
+    int parent, action, nxt, nlev;
+    descend_group<G, K, COUNT>(m, b, b < m.B, gl, rands, L, counters, nullptr, parent, action, nxt, nlev);
     if (b < m.B && gl == 0) { parents[b] = (int16_t)parent; actions[b] = (int16_t)action; }
 }
 
@@ -702,7 +714,7 @@ __global__ void __launch_bounds__(256) hex_observe_kernel(const uint8_t* board, 
 struct Search {
     uint16_t* logits; uint16_t* v; uint16_t* w; int16_t* n; int16_t* children; int16_t* parents; int16_t* relation;
     uint16_t* rewards; uint8_t* terminal; uint8_t* boards; int32_t* seats; const uint16_t* c_puct; uint32_t* qrange;
-    const float* exp_table; int B, T, S; int obs_f16;
+    const float* exp_table; int B, T, S; int obs_f16; int16_t* path;
 };
 
 template <int G, int K, bool COUNT>
@@ -724,8 +736,9 @@ __global__ void __launch_bounds__(BL_WAVE) sim_expand_kernel(Search s, int sim, 
 
     long long tk0 = 0, tk1 = 0;
     if (COUNT) tk0 = clock64();
-    int parent, action, nxt;
-    descend_group<G, K, COUNT>(m, b, act, gl, rands, L, counters, parent, action, nxt);
+    int parent, action, nxt, nlev;
+    int16_t* path = s.path ? s.path + (long)b * (T + 2) : nullptr;
+    descend_group<G, K, COUNT>(m, b, act, gl, rands, L, counters, act ? path : nullptr, parent, action, nxt, nlev);
     if (action < 0) action = 0;
     if (COUNT) tk1 = clock64();
 
@@ -772,6 +785,11 @@ __global__ void __launch_bounds__(BL_WAVE) sim_expand_kernel(Search s, int sim, 
         s.rewards[(envbase + leaf) * 2 + 1] = f2h((float)(-win));
         leaves_out[b] = (int16_t)leaf;
         leaf_seats_out[b] = new_seat;
+        if (path) {
+            // evaluated nodes root-first, then the leaf (new, or the terminal node the descent stopped at)
+            path[1 + nlev] = (int16_t)leaf;
+            path[0] = (int16_t)(nlev + 1);
+        }
     }
     if (COUNT && gl == 0) {
         unsigned long long* e = counters + 12 * (long)b;
@@ -856,22 +874,52 @@ __global__ void __launch_bounds__(BL_WAVE) sim_finish_kernel(Search s, int sim, 
             if (it < iters && a < A) dst[a] = f2h(e[it] - mx - lsum);
         }
     }
-    // ---- value head + backup walk, lanes 0 (seat 0) and 1 (seat 1)
-    if (lane < 2) {
-        const uint16_t tv = f2h(tanhf(h2f(value_raw[b])));
-        const int mover = leaf_seats[b];
-        const uint16_t vb = (lane == mover) ? tv : (uint16_t)(tv ^ 0x8000u);
-        s.v[(envbase + leaf) * 2 + lane] = vb;
-        backup_walk(s.rewards, s.parents, s.terminal, s.w, s.n, envbase, 2, lane, leaf, h2f(vb));
+    // ---- value head
+    const uint16_t tv = f2h(tanhf(h2f(value_raw[b])));
+    const int mover = leaf_seats[b];
+    const uint16_t vb0 = (mover == 0) ? tv : (uint16_t)(tv ^ 0x8000u), vb1 = (uint16_t)(vb0 ^ 0x8000u);
+    if (lane == 0) { s.v[(envbase + leaf) * 2] = vb0; s.v[(envbase + leaf) * 2 + 1] = vb1; }
+    // ---- backup (cuda.cu:205-236) along the path bl_sim_expand recorded (root first, leaf last): lane j loads node j's
+    // fields in one round trip instead of chasing parents[] leaf-to-root; v then flows leaf -> root through registers.
+    const int16_t* path = s.path + (long)b * (T + 2);
+    const int len = path[0];
+    float v0 = h2f(vb0), v1 = h2f(vb1);
+    for (int base = ((len - 1) / BL_WAVE) * BL_WAVE; base >= 0; base -= BL_WAVE) {
+        const int j = base + lane;
+        const bool in = j < len;
+        long i = envbase;
+        int term = 0, nn = 0;
+        float r0 = 0.f, r1 = 0.f, w0 = 0.f, w1 = 0.f;
+        if (in) {
+            i = envbase + path[1 + j];
+            term = s.terminal[i]; nn = s.n[i];
+            r0 = h2f(s.rewards[i * 2]); r1 = h2f(s.rewards[i * 2 + 1]);
+            w0 = h2f(s.w[i * 2]); w1 = h2f(s.w[i * 2 + 1]);
+        }
+        const int top_j = min(len - 1 - base, BL_WAVE - 1);
+        for (int l = top_j; l >= 0; l--) {
+            if (__builtin_amdgcn_readlane(term, l)) { v0 = 0.f; v1 = 0.f; }
+            v0 += readlane_f(r0, l); v1 += readlane_f(r1, l);
+            if (lane == l) { w0 = h2f(f2h(w0 + h2f(f2h(v0)))); w1 = h2f(f2h(w1 + h2f(f2h(v1)))); }
+        }
+        if (in) {
+            s.w[i * 2] = f2h(w0); s.w[i * 2 + 1] = f2h(w1);
+            s.n[i] = (int16_t)(nn + 2);      // n += 1 once per seat (cuda.cu:230)
+        }
     }
-    __syncthreads();   // workgroup-scope release/acquire: the walk's stores are visible to the scan below
+    __syncthreads();   // workgroup-scope release/acquire: the stores above are visible to the scan below
     uint32_t nmin = 0, vmax = 0;
     for (int e = lane; e < T; e += BL_WAVE) {
         const float den = (float)s.n[envbase + e] + 1.e-4f;
         const uint32_t e0 = enc(h2f(s.w[(envbase + e) * 2]) / den), e1 = enc(h2f(s.w[(envbase + e) * 2 + 1]) / den);
         nmin = max(nmin, max(~e0, ~e1)); vmax = max(vmax, max(e0, e1));
     }
-    qrange_publish(s.qrange + 2 * BL_QSLOTS * (sim + 1), nmin, vmax, blockIdx.x % BL_QSLOTS);
+    nmin = wave_max_u32(nmin); vmax = wave_max_u32(vmax);
+    if (lane == 0) {
+        uint32_t* p = s.qrange + 2 * BL_QSLOTS * (sim + 1) + 2 * (blockIdx.x % BL_QSLOTS);
+        if (nmin > __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(p, nmin);
+        if (vmax > __hip_atomic_load(p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(p + 1, vmax);
+    }
 }
 
 // ReZero residual under fp16 autocast, fused (networks.py:17-18): x_out = x + alpha*y with torch's rounding points --
@@ -1134,7 +1182,7 @@ static int search_check(const bl_search_t* s) {
 static Search to_search(const bl_search_t* s) {
     return Search{(uint16_t*)s->logits, (uint16_t*)s->v, (uint16_t*)s->w, s->n, s->children, s->parents, s->relation,
                   (uint16_t*)s->rewards, s->terminal, s->boards, s->seats, (const uint16_t*)s->c_puct, s->qrange,
-                  s->exp_table, s->B, s->T, s->boardsize, s->obs_f16};
+                  s->exp_table, s->B, s->T, s->boardsize, s->obs_f16, s->path};
 }
 
 static int sim_expand_impl(const bl_search_t* s, int sim, const void* rands, int16_t* leaves, void* obs, uint8_t* valid,
@@ -1187,7 +1235,7 @@ int bl_sim_finish(const bl_search_t* s, int sim, const int16_t* leaves, const vo
                   const uint8_t* valid, const int32_t* leaf_seats, bl_stream_t stream) {
     int rc = search_check(s);
     if (rc) return rc;
-    if (!leaves || !policy_raw || !value_raw || !valid || !leaf_seats || sim < 1 || sim >= s->T) return BL_EINVAL;
+    if (!leaves || !policy_raw || !value_raw || !valid || !leaf_seats || !s->path || sim < 1 || sim >= s->T) return BL_EINVAL;
     const int A = s->boardsize * s->boardsize;
     int np2 = 1; while (np2 < A) np2 *= 2;
     const int W = np2 < 64 ? np2 : 64, iters = np2 / W;

@@ -103,6 +103,7 @@ class MCTS:
             self._obs = e(B, bs, bs, 2, dtype=torch.half if obs_half else torch.float)
             self._valid = e(B, A, dtype=torch.bool)
             self._leaf_seats = e(B, dtype=torch.int)
+            self._path = e(B, T + 2, dtype=torch.short)
             self.counters = torch.zeros((B, 12), dtype=torch.int64, device=dev) if count else None
             self._search = _native.Search(
                 logits=self.decisions.logits.data_ptr(), v=self.decisions.v.data_ptr(), w=self.stats.w.data_ptr(),
@@ -110,7 +111,8 @@ class MCTS:
                 relation=self.tree.relation.data_ptr(), rewards=self.transitions.rewards.data_ptr(),
                 terminal=self.transitions.terminal.data_ptr(), boards=self.worlds.board.data_ptr(),
                 seats=self.worlds.seats.data_ptr(), c_puct=self.c_puct.data_ptr(), qrange=self._qrange.data_ptr(),
-                exp_table=self._exp.data_ptr(), B=B, T=T, boardsize=bs, obs_f16=int(obs_half))
+                exp_table=self._exp.data_ptr(), B=B, T=T, boardsize=bs, obs_f16=int(obs_half),
+                path=self._path.data_ptr())
             with torch.cuda.device(dev):
                 _native.check(_native.lib().bl_sim_init(ctypes.byref(self._search), world.board.contiguous().data_ptr(),
                                                         world.seats.int().contiguous().data_ptr(), _native.stream(dev)))

@@ -109,6 +109,8 @@ typedef struct {
     int B, T, boardsize;
     int obs_f16;         /* 0: bl_sim_expand writes obs as f32 (the reference's layout); 1: as f16 (what fp16 autocast feeds
                             the first Linear anyway; exact, the planes are 0/1) */
+    int16_t* path;       /* (B,T+2) i16 scratch or NULL: bl_sim_expand records each descent as [len, root, ..., leaf] so
+                            that bl_sim_finish can back up without chasing parents[]; required by bl_sim_finish */
 } bl_search_t;
 
 /* mcts/__init__.py:113-129 + hex/__init__.py:148-195 for simulation number `sim` (1..T-1):

@@ -38,7 +38,7 @@ def test_argument_validation_without_gpu():
     assert L.bl_hex_observe(one, one, one, 4, 33, None) == -2
     assert L.bl_mcts_descend(*([one] * 10), 1, 1, 2000, 1, one, one, None) == -2
     assert b'limits' in L.bl_strerror(-2)
-    assert ctypes.sizeof(_native.Search) == 14 * 8 + 3 * 4 + 4
+    assert ctypes.sizeof(_native.Search) == 14 * 8 + 4 * 4 + 8
 
 
 def test_exp_table_is_host_libm(oracle):
