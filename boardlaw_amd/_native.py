@@ -9,7 +9,7 @@ import torch
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIBPATH = os.path.join(HERE, 'libboardlaw_amd.so')
-QRANGE_WORDS = 128
+QRANGE_WORDS = 4096
 
 _vp, _i = ctypes.c_void_p, ctypes.c_int
 

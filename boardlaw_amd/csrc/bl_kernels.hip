@@ -18,7 +18,9 @@
 
 #pragma clang fp contract(off)
 
-#define BL_QSLOTS 64          // qrange state: 64 slots x {~enc(min), enc(max)}
+#define BL_QSLOTS 64          // qrange state: 64 slots x {~enc(min), enc(max)} ...
+#define BL_QSTRIDE 64         // ... one slot per 256 B (64 words): same-line atomics serialise in L2 (~12 ns each)
+#define BL_QWORDS (BL_QSLOTS * BL_QSTRIDE)
 #define BL_WAVE 64
 
 namespace bl {
@@ -62,7 +64,7 @@ struct Tree {
     const void* seats;        // (B,T) i16 (reference struct) or i32 (worlds.seats, fused path)
     const uint8_t* terminal;  // (B,T)
     const int16_t* children;  // (B,T,A)
-    const uint32_t* qrange;   // BL_QSLOTS x 2
+    const uint32_t* qrange;   // BL_QWORDS
     const float* exp_table;   // 65536
     int B, T, A, S;
     int seats_i32;
@@ -75,7 +77,7 @@ __device__ __forceinline__ int load_seat(const Tree& m, long i) {
 // Reduce the 64 qrange slots: every lane of the wave returns {lo, hi}.  transition_q, cuda.cu:101-105.
 __device__ __forceinline__ void load_qrange(const uint32_t* qr, float& lo, float& hi) {
     const int lane = threadIdx.x & 63;
-    uint32_t a = qr[2 * lane], b = qr[2 * lane + 1];
+    uint32_t a = qr[BL_QSTRIDE * lane], b = qr[BL_QSTRIDE * lane + 1];
     a = gmaxu<64>(a); b = gmaxu<64>(b);
     lo = dec(~a); hi = dec(b);
 }
@@ -564,7 +566,7 @@ __global__ void __launch_bounds__(BL_WAVE) root_kernel(Tree m, uint16_t* probs) 
 __device__ __forceinline__ void qrange_publish(uint32_t* qr, uint32_t nmin, uint32_t vmax, int slot) {
     nmin = gmaxu<64>(nmin); vmax = gmaxu<64>(vmax);
     if ((threadIdx.x & 63) == 0) {
-        uint32_t* p = qr + 2 * slot;
+        uint32_t* p = qr + BL_QSTRIDE * slot;
         if (nmin > __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(p, nmin);
         if (vmax > __hip_atomic_load(p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(p + 1, vmax);
     }
@@ -731,7 +733,7 @@ __global__ void __launch_bounds__(BL_WAVE) sim_expand_kernel(Search s, int sim, 
 
     Tree m;
     m.logits = s.logits; m.w = s.w; m.n = s.n; m.c_puct = s.c_puct; m.seats = s.seats; m.terminal = s.terminal;
-    m.children = s.children; m.qrange = s.qrange + 2 * BL_QSLOTS * sim; m.exp_table = s.exp_table;
+    m.children = s.children; m.qrange = s.qrange + (long)BL_QWORDS * sim; m.exp_table = s.exp_table;
     m.B = s.B; m.T = T; m.A = A; m.S = 2; m.seats_i32 = 1;
 
     long long tk0 = 0, tk1 = 0;
@@ -828,7 +830,7 @@ __global__ void __launch_bounds__(BL_WAVE) sim_backup_kernel(Search s, int sim, 
             nmin = max(nmin, max(~e0, ~e1)); vmax = max(vmax, max(e0, e1));
         }
     }
-    qrange_publish(s.qrange + 2 * BL_QSLOTS * (sim + 1), nmin, vmax, blockIdx.x % BL_QSLOTS);
+    qrange_publish(s.qrange + (long)BL_QWORDS * (sim + 1), nmin, vmax, blockIdx.x % BL_QSLOTS);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -916,7 +918,7 @@ __global__ void __launch_bounds__(BL_WAVE) sim_finish_kernel(Search s, int sim, 
     }
     nmin = wave_max_u32(nmin); vmax = wave_max_u32(vmax);
     if (lane == 0) {
-        uint32_t* p = s.qrange + 2 * BL_QSLOTS * (sim + 1) + 2 * (blockIdx.x % BL_QSLOTS);
+        uint32_t* p = s.qrange + (long)BL_QWORDS * (sim + 1) + BL_QSTRIDE * (blockIdx.x % BL_QSLOTS);
         if (nmin > __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(p, nmin);
         if (vmax > __hip_atomic_load(p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(p + 1, vmax);
     }
@@ -978,7 +980,7 @@ __global__ void __launch_bounds__(256) sim_init_kernel(Search s, const uint8_t* 
     grid_fill(s.n, B * T * 2, 0);
     grid_fill(s.rewards, B * T * 2 * 2, 0);
     grid_fill(s.terminal, B * T, 0);
-    grid_fill(s.qrange, (T + 1) * 2 * BL_QSLOTS * sizeof(uint32_t), 0);
+    grid_fill(s.qrange, (T + 1) * (size_t)BL_QWORDS * sizeof(uint32_t), 0);
     const long total = (long)(B * T * A);
     for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
         const long node = idx / (long)A;
@@ -992,8 +994,8 @@ __global__ void __launch_bounds__(256) sim_init_kernel(Search s, const uint8_t* 
 // descend #1 sees the untouched stats: every q is 0/1e-4 = 0, so its range is {0, 0}.  Separate launch: it must land
 // after the grid-wide zeroing of qrange above.
 __global__ void sim_init_qrange_kernel(Search s) {
-    s.qrange[2 * BL_QSLOTS * 1 + 0] = ~enc(0.f);
-    s.qrange[2 * BL_QSLOTS * 1 + 1] = enc(0.f);
+    s.qrange[BL_QWORDS * 1 + 0] = ~enc(0.f);
+    s.qrange[BL_QWORDS * 1 + 1] = enc(0.f);
 }
 
 __global__ void __launch_bounds__(256) zero_words_kernel(uint32_t* p, int n) {
@@ -1082,7 +1084,7 @@ int bl_exp_table_host(float* t) {
 int bl_qrange_decode(const uint32_t* st, float* mm) {
     if (!st || !mm) return BL_EINVAL;
     uint32_t a = 0, b = 0;
-    for (int i = 0; i < BL_QSLOTS; i++) { if (st[2 * i] > a) a = st[2 * i]; if (st[2 * i + 1] > b) b = st[2 * i + 1]; }
+    for (int i = 0; i < BL_QSLOTS; i++) { if (st[BL_QSTRIDE * i] > a) a = st[BL_QSTRIDE * i]; if (st[BL_QSTRIDE * i + 1] > b) b = st[BL_QSTRIDE * i + 1]; }
     mm[0] = dec(~a); mm[1] = dec(b);
     return BL_OK;
 }
@@ -1090,7 +1092,7 @@ int bl_qrange_decode(const uint32_t* st, float* mm) {
 int bl_mcts_qrange(const void* w, const int16_t* n, int B, int T, int S, uint32_t* st, bl_stream_t stream) {
     if (!w || !n || !st || B <= 0 || T <= 0 || S <= 0) return BL_EINVAL;
     hipStream_t hs = (hipStream_t)stream;
-    hipLaunchKernelGGL(zero_words_kernel, dim3(1), dim3(128), 0, hs, st, 2 * BL_QSLOTS);
+    hipLaunchKernelGGL(zero_words_kernel, dim3(1), dim3(256), 0, hs, st, BL_QWORDS);
     const long nodes = (long)B * T;
     int blocks = (int)((nodes + 255) / 256); if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(qrange_kernel, dim3(blocks), dim3(256), 0, hs, (const uint16_t*)w, n, nodes, S, st);
@@ -1261,7 +1263,7 @@ int bl_sim_root(const bl_search_t* s, int sim, void* probs, bl_stream_t stream) 
     if (!probs || sim < 1 || sim > s->T) return BL_EINVAL;
     const int A = s->boardsize * s->boardsize;
     Tree m{(const uint16_t*)s->logits, (const uint16_t*)s->w, s->n, (const uint16_t*)s->c_puct, s->seats, s->terminal,
-           s->children, s->qrange + 2 * BL_QSLOTS * sim, s->exp_table, s->B, s->T, A, 2, 1};
+           s->children, s->qrange + (long)BL_QWORDS * sim, s->exp_table, s->B, s->T, A, 2, 1};
     const int G = pick_group(s->B, A), K = pick_k(A, G);
     const int per = lds_bytes(A, false);
     const int blocks = (s->B + 64 / G - 1) / (64 / G);

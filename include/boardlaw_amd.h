@@ -30,7 +30,7 @@ extern "C" {
 #define BL_ETOOBIG (-2)    /* A, T or S beyond what the kernels support (A <= 1024, T <= 32767, S <= 8, board <= 32) */
 #define BL_ELAUNCH (-3)    /* hipGetLastError() != hipSuccess after the launch (reference: C10_CUDA_CHECK) */
 
-#define BL_QRANGE_WORDS 128 /* u32 words in one q-range state: 64 slots x {~enc(min), enc(max)} */
+#define BL_QRANGE_WORDS 4096 /* u32 words in one q-range state: 64 slots, one per 256 B, words 0/1 = {~enc(min), enc(max)} */
 
 typedef void* bl_stream_t; /* hipStream_t */
 
@@ -44,9 +44,9 @@ int bl_exp_table_host(float* host_table /* 65536 floats, HOST memory */);
 
 /* ---- transition_q's batch-global range (boardlaw/mcts/cpp/cuda.cu:101-105) --------------------------------------
  * qrange_state: BL_QRANGE_WORDS x u32, device: 64 slots of {max of ~enc(q), max of enc(q)} over the slot's share of
- * the B*T*S values q = f32(w)/(f32(n)+1e-4f); enc = the order-preserving float->u32 map.  Spreading the atomics
- * over 64 addresses keeps the reduction off a single L2 atomic unit; consumers max-reduce the 64 slots in one wave
- * load.  bl_mcts_qrange zeroes the state itself (a kernel, not a memset node) and reduces into it; shards that want the reference's
+ * the B*T*S values q = f32(w)/(f32(n)+1e-4f); enc = the order-preserving float->u32 map.  One slot per 256 B:
+ * atomics on one cache line serialise in L2 (about 12 ns each, measured: 4096 waves x 2 atomics on 4 lines cost
+ * ~25 us), on 64 lines they do not; consumers max-reduce the 64 slots with one wave-wide load.  bl_mcts_qrange zeroes the state itself (a kernel, not a memset node) and reduces into it; shards that want the reference's
  * *global* normalisation all-reduce(MAX) the words across ranks.  bl_qrange_decode turns a HOST copy into {min,max}. */
 int bl_mcts_qrange(const void* w /*f16 (B,T,S)*/, const int16_t* n /*(B,T)*/, int B, int T, int S,
                    uint32_t* qrange_state, bl_stream_t stream);

@@ -53,8 +53,8 @@ def test_qrange_decode_roundtrip():
     def enc(f):
         b = np.float32(f).view(np.uint32)
         return np.uint32(~b) if b & 0x80000000 else np.uint32(b | 0x80000000)
-    st = np.zeros(128, np.uint32)
-    st[2 * 5] = ~enc(-3.5); st[2 * 5 + 1] = enc(0.25); st[2 * 9] = ~enc(1.0); st[2 * 9 + 1] = enc(-7.0)
+    st = np.zeros(4096, np.uint32)
+    st[64 * 5] = ~enc(-3.5); st[64 * 5 + 1] = enc(0.25); st[64 * 9] = ~enc(1.0); st[64 * 9 + 1] = enc(-7.0)
     assert _native.qrange_decode(torch.from_numpy(st.view(np.int32))).tolist() == [-3.5, 0.25]
 
 
