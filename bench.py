@@ -112,15 +112,11 @@ def main():
     ap.add_argument('--eager', action='store_true', help='launch kernel by kernel instead of replaying a HIP graph per move')
     args = ap.parse_args()
 
-    rank = int(os.environ.get('RANK', 0)); world = int(os.environ.get('WORLD_SIZE', 1))
-    local = int(os.environ.get('LOCAL_RANK', 0))
     assert torch.cuda.is_available(), 'bench.py needs an MI355X; there is no CPU path'
+    from boardlaw_amd import parallel
+    rank, world, local = parallel.env_rank()
     torch.cuda.set_device(local)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+    parallel.init('nccl')       # RCCL; used only for the barrier and the max-over-ranks of the elapsed time
 
     from boardlaw_amd import _native, networks
     from boardlaw_amd.hex import Hex
@@ -146,12 +142,7 @@ def main():
     for _ in range(args.warmup):
         worlds = move(worlds)
 
-    def barrier():
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-
+    barrier = parallel.barrier
     barrier()
     timer.on = args.eager          # graph replays cannot carry per-launch events; see the probe below
     t0 = time.perf_counter()
@@ -160,10 +151,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     timer.on = False
-    if dist is not None:
-        t = torch.tensor([elapsed], device='cuda', dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = parallel.max_over_ranks(elapsed)
 
     sims_total = world * args.envs * NODES * args.steps
     value = sims_total / elapsed
@@ -183,6 +171,11 @@ def main():
         kernel_us = timer.mean_us()
         per_launch = expand_bytes_per_env(A, S, d, k) * args.envs
         achieved = per_launch / (kernel_us * 1e-6) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, 'profiles', 'r01_traffic.json')
+        if args.envs == ENVS and os.path.exists(tpath):
+            # HBM-side bytes per launch from rocprofv3 PMC passes (FETCH_SIZE + WRITE_SIZE), see profiles/README.md
+            traffic = json.load(open(tpath))['traffic_bytes_per_launch']
         out = {
             'metric': 'mcts_sims_per_sec', 'value': value, 'unit': 'sims/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps, 'higher_is_better': True,
@@ -195,15 +188,15 @@ def main():
                        'bytes_per_sim_whole_path': round(total_bytes_per_sim(A, S, NODES, d, k), 1),
                        'hbm_frac_whole_path': total_bytes_per_sim(A, S, NODES, d, k) * value / world / (HBM_PEAK_GBS * 1e9)},
             'roofline': {'bound': 'hbm', 'kernel': 'bl::sim_expand_kernel', 'achieved': achieved, 'peak': HBM_PEAK_GBS,
-                         'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS, 'traffic': None,
+                         'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
                          'kernel_us': kernel_us, 'bytes_per_launch': per_launch, 'launches_timed': len(timer.pairs),
                          'timing': 'HIP events around every launch ' + ('inside the timed region' if args.eager else 'in an eager re-run of the same moves right after the timed (graph-replay) region')},
         }
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline()
         print(json.dumps(out))
-    if dist is not None:
-        dist.destroy_process_group()
+    if world > 1:
+        torch.distributed.destroy_process_group()
 
 
 if __name__ == '__main__':

@@ -67,7 +67,7 @@ class LeafWorlds:
 class MCTS:
 
     def __init__(self, world, n_nodes=64, c_puct=1 / 16, noise_eps=.25, alpha_scale=10, fused=None, rng=None,
-                 count=False, obs_half=False):
+                 count=False, obs_half=False, qrange_sync=None):
         """c_puct high: concentrates on prior; c_puct low: concentrates on value (mcts/__init__.py:29-33)."""
         from .. import hex as hexmod
         self.device = world.device
@@ -78,6 +78,9 @@ class MCTS:
         self.n_actions = int(np.prod(world.action_space))
         self.noise_eps, self.alpha_scale = noise_eps, alpha_scale
         self.rng = rng or TorchRng()
+        # optional callable(state_row) run after every backup on the q-range row the next descent will read, e.g.
+        # parallel.allreduce_qrange: env shards on several GPUs then normalise q over ALL envs like one big batch
+        self.qrange_sync = qrange_sync
         self.fused = isinstance(world, hexmod.Hex) if fused is None else fused
         if self.fused and not isinstance(world, hexmod.Hex):
             raise ValueError('The fused path is Hex-only')
@@ -216,6 +219,8 @@ class MCTS:
             raise ValueError('Called simulate more times than were declared in the constructor')
         if self.fused:
             self._simulate_fused(network)
+            if self.qrange_sync is not None:
+                self.qrange_sync(self._qrange[self.sim + 1])
         else:
             self._simulate_generic(network)
         self.sim += 1

@@ -1,0 +1,86 @@
+"""One process per GPU.  Self-play shards along the env axis with no data-path collective: every rank owns
+an independent shard of every SoA array and a network replica.  The reference has no collective at all (its multi-GPU
+mode is N independent jobs, boardlaw/main.py:202-209); the only exchange the search itself can need is the batch-global
+q range of transition_q (boardlaw/mcts/cpp/cuda.cu:101-105), provided here as an opt-in all-reduce(MAX) of the q-range
+state so that N shards of B envs reproduce one device running N*B envs bit for bit.
+
+Backend: "nccl" (= RCCL over xGMI) on GPUs, "gloo" on CPU (tests)."""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def env_rank():
+    return int(os.environ.get('RANK', 0)), int(os.environ.get('WORLD_SIZE', 1)), int(os.environ.get('LOCAL_RANK', 0))
+
+
+def init(backend=None):
+    """Joins the process group described by RANK/WORLD_SIZE/MASTER_* (torch.distributed.run sets them). Returns
+    (rank, world).  World size 1 needs no group."""
+    rank, world, local = env_rank()
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29500')
+        if backend is None:
+            backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+        kwargs = {}
+        if backend == 'nccl':
+            torch.cuda.set_device(local)
+            kwargs['device_id'] = torch.device('cuda', local)
+        dist.init_process_group(backend, rank=rank, world_size=world, **kwargs)
+    return rank, world
+
+
+def shard(n_total, rank, world):
+    """Contiguous, near-equal slice of an env axis of length n_total for `rank` (first ranks take the remainder)."""
+    base, extra = divmod(n_total, world)
+    start = rank * base + min(rank, extra)
+    return slice(start, start + base + (1 if rank < extra else 0))
+
+
+def barrier():
+    if torch.cuda.is_available():
+        torch.cuda.synchronize()
+    if dist.is_initialized():
+        dist.barrier()
+    if torch.cuda.is_available():
+        torch.cuda.synchronize()
+
+
+def max_over_ranks(value, device=None):
+    """MAX of a python float over ranks (the bench's elapsed time)."""
+    if not dist.is_initialized():
+        return float(value)
+    device = device or ('cuda' if dist.get_backend() == 'nccl' else 'cpu')
+    t = torch.tensor([value], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def sum_over_ranks(value, device=None):
+    if not dist.is_initialized():
+        return float(value)
+    device = device or ('cuda' if dist.get_backend() == 'nccl' else 'cpu')
+    t = torch.tensor([value], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return float(t.item())
+
+
+def merge_qrange(*states):
+    """Element-wise unsigned MAX of q-range states (int32 storage of u32 words): the state of the union of the shards.
+    This is the local form of allreduce_qrange."""
+    wide = torch.stack([s.to(torch.int64) & 0xffffffff for s in states]).amax(0)
+    return torch.where(wide >= 2**31, wide - 2**32, wide).to(torch.int32)
+
+
+def allreduce_qrange(state):
+    """In-place all-reduce(MAX) of a q-range state (int32 storage of u32 words, any shape): afterwards every rank holds
+    the range over the union of all shards' envs.  The words are unsigned, the collective compares signed, so they
+    travel as int64."""
+    if not dist.is_initialized():
+        return state
+    wide = state.to(torch.int64) & 0xffffffff
+    dist.all_reduce(wide, op=dist.ReduceOp.MAX)
+    state.copy_(torch.where(wide >= 2**31, wide - 2**32, wide).to(torch.int32))
+    return state

@@ -450,3 +450,38 @@ def test_raw_path_equals_torch_heads_path():
                      (results[0].decisions.v, other.decisions.v)]:
             assert np.array_equal(to_np(a), to_np(b))
         assert torch.equal(results[0].root_probs(), other.root_probs())
+
+
+def test_sharded_search_with_merged_qrange_equals_unsharded(oracle):
+    """SURVEY 8e option 2: two env shards that exchange their q-range state (element-wise MAX, what
+    parallel.allreduce_qrange does over RCCL) after every backup reproduce the unsharded search bit for bit; without
+    the exchange they do not (transition_q normalises over the whole batch, cuda.cu:101-105)."""
+    from boardlaw_amd import parallel
+    from boardlaw_amd.hex import Hex
+    from boardlaw_amd.mcts import MCTS
+    S, B, T = 7, 512, 24
+    board, seats = premixed(oracle, B, S, 16, seed=99)
+    rands = np.random.default_rng(3).random((T - 1, B, T)).astype(np.float16).view(np.uint16)
+    net = HashNetwork(DEV)
+
+    def start(sl, r):
+        w = Hex(board=torch.from_numpy(board[sl]).to(DEV), seats=torch.from_numpy(seats[sl]).to(DEV))
+        m = MCTS(w, n_nodes=T, rng=ReplayRng(r, DEV), noise_eps=0.)
+        d = net(w); m.plant_root(d.logits, d.v)
+        return m
+
+    full = start(slice(0, B), rands)
+    for _ in range(T - 1):
+        full.simulate(net)
+    for merge in (True, False):
+        a, b = start(slice(0, B // 2), rands[:, :B // 2]), start(slice(B // 2, B), rands[:, B // 2:])
+        for _ in range(T - 1):
+            a.simulate(net); b.simulate(net)
+            if merge:
+                row = parallel.merge_qrange(a._qrange[a.sim], b._qrange[b.sim])
+                a._qrange[a.sim] = row; b._qrange[b.sim] = row
+        same = all(np.array_equal(np.concatenate([to_np(x), to_np(y)]), to_np(z)) for x, y, z in
+                   [(a.stats.n, b.stats.n, full.stats.n), (a.tree.children, b.tree.children, full.tree.children),
+                    (a.stats.w, b.stats.w, full.stats.w)])
+        same = same and np.array_equal(np.concatenate([bits16(a.root_probs()), bits16(b.root_probs())]), bits16(full.root_probs()))
+        assert same == merge
