@@ -109,6 +109,7 @@ def main():
     ap.add_argument('--envs', type=int, default=ENVS, help='envs per GPU (the metric is quoted at 4096)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--plain-network', action='store_true', help='run the nn.Module under autocast instead of the fp16 inference plan')
+    ap.add_argument('--torch-gemms', action='store_true', help='keep the Linears as torch (hipBLASLt) GEMMs instead of the fused MFMA kernel')
     ap.add_argument('--eager', action='store_true', help='launch kernel by kernel instead of replaying a HIP graph per move')
     args = ap.parse_args()
 
@@ -129,7 +130,7 @@ def main():
     net = networks.FCModel(worlds.obs_space, worlds.action_space, width=WIDTH, depth=DEPTH).cuda()
     worlds = premix(worlds, BOARD * BOARD // 3, gen)
     torch.manual_seed(1 + rank)
-    agent = MCTSAgent(net if args.plain_network else networks.Inference(net), n_nodes=NODES, graph=not args.eager)
+    agent = MCTSAgent(net if args.plain_network else networks.Inference(net, fused=not args.torch_gemms), n_nodes=NODES, graph=not args.eager)
 
     timer = TimedExpand(lib)
     lib.bl_sim_expand = timer

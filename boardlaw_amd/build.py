@@ -7,7 +7,7 @@ import subprocess
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
-SOURCES = [os.path.join(HERE, 'csrc', 'bl_kernels.hip')]
+SOURCES = [os.path.join(HERE, 'csrc', 'bl_kernels.hip'), os.path.join(HERE, 'csrc', 'bl_mlp.hip')]
 HEADERS = [os.path.join(ROOT, 'include', 'boardlaw_amd.h')]
 LIB = os.path.join(HERE, 'libboardlaw_amd.so')
 

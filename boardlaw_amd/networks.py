@@ -43,6 +43,13 @@ class FCModel(nn.Module):
         return self.policy.raw(neck), self.value.core(neck).squeeze(-1)
 
 
+def pack_fragment_major(m):
+    """(N, K) f16 -> the layout bl_mlp_forward_f16 streams: [N/32][K/64][s=4][lane=64][8] with
+    lane = 32*(k-half) + (n % 32); N % 32 == 0, K % 64 == 0."""
+    N, K = m.shape
+    return m.view(N // 32, 32, K // 64, 2, 4, 8).permute(0, 2, 4, 3, 1, 5).contiguous()
+
+
 class Inference:
     """fp16 inference plan for an FCModel inside the search: the same arithmetic as the module under fp16 autocast
     (what the reference runs in MCTS.simulate), issued as 6 GEMMs + 5 elementwise launches instead of ~45:
@@ -50,14 +57,19 @@ class Inference:
       * the ReZero tail x + alpha*y and the next block's relu are one fused kernel (bl_rezero_relu_f16) with torch's
         rounding points;
       * the heads are left to bl_sim_finish.
-    Calling the object runs the wrapped module unchanged (fp32 root evaluation, training).  Results of raw() are
-    bit-identical to FCModel.raw under autocast (tests/test_gpu_parity.py::test_inference_plan_matches_autocast)."""
+    Calling the object runs the wrapped module unchanged (fp32 root evaluation, training).  With fused=False results of
+    raw() are bit-identical to FCModel.raw under autocast (tests/test_gpu_parity.py::test_inference_plan_matches_autocast)."""
 
     wants_half_obs = True
 
-    def __init__(self, model):
+    def __init__(self, model, fused=False):
+        """fused=True additionally runs all Linears as ONE MFMA kernel (bl_mlp_forward_f16) when the width is a multiple
+        of 128: same rounding points, but the GEMMs' summation order is the kernel's own, so outputs equal the autocast
+        module's to f16 rounding rather than bit for bit."""
         self.model = model
+        self.fused = fused
         self._static = None
+        self._packed = None
 
     def __call__(self, worlds):
         return self.model(worlds)
@@ -80,6 +92,13 @@ class Inference:
         srcs += [m.policy.core.weight, m.policy.core.bias, m.value.core.weight, m.value.core.bias]
         return srcs, [getattr(blk, 'α') for blk in blocks[1:]]
 
+    def _fusable(self):
+        m = self.model
+        blocks = list(m.body)
+        W, K0 = blocks[0].weight.shape
+        return (W % 128 == 0 and 128 <= W <= 512 and -(-K0 // 64) * 64 <= W and type(m.policy).__name__ in ('MaskedOutput', 'DiscreteOutput')
+                and blocks[0].weight.is_cuda)
+
     def refresh(self):
         """Re-cast the module's current parameters into the static f16 buffers (in place: safe to capture/replay)."""
         srcs, alphas = self._sources()
@@ -87,10 +106,32 @@ class Inference:
             if self._static is None or self._static[0][0].device != srcs[0].device:
                 self._static = ([torch.empty_like(p, dtype=torch.half) for p in srcs],
                                 [torch.empty((), dtype=torch.float, device=a.device) for a in alphas])
+                self._packed = None
             for dst, src in zip(self._static[0], srcs):
                 dst.copy_(src)
             for dst, src in zip(self._static[1], alphas):
                 dst.copy_(src)
+            if self.fused and self._fusable():
+                # layout of bl_mlp_forward_f16: zero-padded intake, stacked blocks, policy+value head stacked
+                w = self._static[0]
+                W, K0 = w[0].shape
+                D, A = len(alphas), w[-4].shape[0]
+                K0pad, NHpad = -(-K0 // 64) * 64, -(-(A + 1) // 32) * 32
+                if self._packed is None:
+                    dev = w[0].device
+                    z = lambda *s, dtype=torch.half: torch.zeros(s, dtype=dtype, device=dev)
+                    self._packed = dict(w0=z(W, K0pad), wb=z(max(D, 1), W, W), bb=z(max(D, 1), W), al=z(max(D, 1), dtype=torch.float),
+                                        wh=z(NHpad, W), bh=z(NHpad), dims=(W, K0, K0pad, D, A + 1, NHpad))
+                pk = self._packed
+                stage0 = torch.zeros((W, K0pad), dtype=torch.half, device=w[0].device); stage0[:, :K0] = w[0]
+                pk['w0'].view(-1).copy_(pack_fragment_major(stage0).view(-1))
+                for d in range(D):
+                    pk['wb'][d].view(-1).copy_(pack_fragment_major(w[2 + 2 * d]).view(-1))
+                    pk['bb'][d].copy_(w[3 + 2 * d]); pk['al'][d].copy_(self._static[1][d])
+                stageh = torch.zeros((NHpad, W), dtype=torch.half, device=w[0].device)
+                stageh[:A] = w[-4]; stageh[A] = w[-2][0]
+                pk['wh'].view(-1).copy_(pack_fragment_major(stageh).view(-1))
+                pk['bh'][:A].copy_(w[-3]); pk['bh'][A].copy_(w[-1][0])
 
     def raw(self, worlds):
         from . import _native
@@ -99,9 +140,20 @@ class Inference:
         w, alphas = self._static
         L = _native.lib()
         obs = worlds.obs
-        x = F.linear(obs.reshape(obs.shape[0], -1).half(), w[0], w[1])
+        x0 = obs.reshape(obs.shape[0], -1).half().contiguous()
+        st = _native.stream(x0.device)
+        if self.fused and self._packed is not None:
+            pk = self._packed
+            W, K0, K0pad, D, NH, NHpad = pk['dims']
+            M = x0.shape[0]
+            policy = torch.empty((M, NH - 1), dtype=torch.half, device=x0.device)
+            value = torch.empty((M,), dtype=torch.half, device=x0.device)
+            _native.check(L.bl_mlp_forward_f16(x0.data_ptr(), M, K0, pk['w0'].data_ptr(), w[1].data_ptr(), pk['wb'].data_ptr(),
+                                               pk['bb'].data_ptr(), pk['al'].data_ptr(), pk['wh'].data_ptr(), pk['bh'].data_ptr(),
+                                               W, D, K0pad, NH, NHpad, policy.data_ptr(), value.data_ptr(), st))
+            return policy, value
+        x = F.linear(x0, w[0], w[1])
         r = F.relu(x)
-        st = _native.stream(x.device)
         for i, alpha in enumerate(alphas):
             y = F.linear(r, w[2 + 2 * i], w[3 + 2 * i])
             x_new, r = torch.empty_like(x), torch.empty_like(x)

@@ -485,3 +485,31 @@ def test_sharded_search_with_merged_qrange_equals_unsharded(oracle):
                     (a.stats.w, b.stats.w, full.stats.w)])
         same = same and np.array_equal(np.concatenate([bits16(a.root_probs()), bits16(b.root_probs())]), bits16(full.root_probs()))
         assert same == merge
+
+
+@pytest.mark.parametrize('S,width,depth,B', [(9, 512, 4, 4096), (7, 128, 4, 1000), (8, 256, 4, 33), (6, 128, 1, 64), (13, 512, 2, 300), (3, 128, 4, 5000)])
+def test_fused_mlp_matches_autocast(S, width, depth, B):
+    """bl_mlp_forward_f16 (one MFMA kernel for all Linears) vs the module under fp16 autocast: same rounding points,
+    different GEMM summation order => a tolerance test.  Tolerance: 3 f16 ulps of the largest activation scale plus
+    1% relative, on the pre-head outputs."""
+    from boardlaw_amd import networks, heads
+    torch.manual_seed(S)
+    net = networks.FCModel(heads.Tensor((S, S, 2)), heads.Masked(S * S), width=width, depth=depth).to(DEV)
+    with torch.no_grad():
+        for blk in list(net.body)[1:]:
+            getattr(blk, 'α').fill_(float(torch.randn(()) * 0.5))
+    class W_: pass
+    w = W_(); w.obs = (torch.rand(B, S, S, 2, device=DEV) < .3).half()
+    fused = networks.Inference(net, fused=True)
+    fused.refresh()
+    assert fused._packed is not None
+    with torch.no_grad(), torch.autocast('cuda'):
+        p0, v0 = net.raw(w)
+        p1, v1 = fused.raw(w)
+    assert p1.shape == p0.shape and v1.shape == v0.shape and p1.dtype == torch.half
+    for a, b in ((p0.float(), p1.float()), (v0.float(), v1.float())):
+        tol = 3 * 2**-10 * a.abs().max().clamp(min=1.) + 0.01 * a.abs()
+        assert ((a - b).abs() <= tol).all(), float((a - b).abs().max())
+    # and the overwhelming majority of outputs should be bit-identical or 1 ulp off
+    close = ((p0.float() - p1.float()).abs() <= 2**-9 * p0.float().abs().clamp(min=2**-5)).float().mean()
+    assert close > 0.99, float(close)
