@@ -121,7 +121,7 @@ def main():
 
     from boardlaw_amd import _native, networks
     from boardlaw_amd.hex import Hex
-    from boardlaw_amd.mcts import MCTSAgent
+    from boardlaw_amd.mcts import MCTSAgent, MoveRng
     lib = _native.lib()
 
     gen = torch.Generator(device='cuda'); gen.manual_seed(1000 + rank)
@@ -130,7 +130,7 @@ def main():
     net = networks.FCModel(worlds.obs_space, worlds.action_space, width=WIDTH, depth=DEPTH).cuda()
     worlds = premix(worlds, BOARD * BOARD // 3, gen)
     torch.manual_seed(1 + rank)
-    agent = MCTSAgent(net if args.plain_network else networks.Inference(net, fused=not args.torch_gemms), n_nodes=NODES, graph=not args.eager)
+    agent = MCTSAgent(net if args.plain_network else networks.Inference(net, fused=not args.torch_gemms), n_nodes=NODES, graph=not args.eager, rng=MoveRng())
 
     timer = TimedExpand(lib)
     lib.bl_sim_expand = timer
@@ -161,7 +161,7 @@ def main():
         A, S = BOARD * BOARD, 2
         if not args.eager:
             # the same moves launched kernel by kernel, only to bracket every bl_sim_expand launch with HIP events
-            probe = MCTSAgent(agent.network, n_nodes=NODES, graph=False)
+            probe = MCTSAgent(agent.network, n_nodes=NODES, graph=False, rng=MoveRng())
             timer.on = True
             for _ in range(min(args.steps, 5)):
                 worlds, _ = worlds.step(probe(worlds).actions, check=False)

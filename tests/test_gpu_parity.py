@@ -513,3 +513,17 @@ def test_fused_mlp_matches_autocast(S, width, depth, B):
     # and the overwhelming majority of outputs should be bit-identical or 1 ulp off
     close = ((p0.float() - p1.float()).abs() <= 2**-9 * p0.float().abs().clamp(min=2**-5)).float().mean()
     assert close > 0.99, float(close)
+
+
+def test_move_rng_serves_one_block_per_move():
+    from boardlaw_amd import hex, networks
+    from boardlaw_amd.mcts import MCTSAgent, MoveRng, mcts
+    torch.manual_seed(0)
+    worlds = hex.Hex.initial(128, 5, device=DEV)
+    net = networks.FCModel(worlds.obs_space, worlds.action_space, width=32, depth=2).to(DEV)
+    rng = MoveRng()
+    m = mcts(worlds, net, n_nodes=16, rng=rng)
+    assert rng.block.shape == (15, 128, 16) and rng.block.dtype == torch.half and rng.i == 15
+    assert (to_np(m.stats.n)[:, 0] == 30).all()
+    d = MCTSAgent(net, n_nodes=16, graph=True, rng=MoveRng())(worlds)
+    assert worlds.valid.gather(1, d.actions[:, None]).all()
