@@ -1019,12 +1019,12 @@ static int forced_group() {
 static int pick_group(int B, int A) {
     const int f = forced_group();
     if ((f == 8 || f == 16 || f == 32 || f == 64) && (A + f - 1) / f <= 16) return f;
-    // Smallest group that keeps <= 16 actions per lane, widened while the launch has fewer than 4 waves for each of
-    // the chip's 1024 SIMDs (256 CUs x 4): a descent is one long dependent chain (loads -> Newton folds -> draw), so
-    // what hides its latency is other waves on the SIMD; lanes idling in the serial fold are the cheaper waste.
-    int G = 8;
-    while (G < 64 && (A + G - 1) / G > 16) G *= 2;
-    while (G < 64 && (long)B * G / 64 < 4096) G *= 2;
+    // One wave per env whenever the action count allows (A <= 64 x 16): that is the DPP path (no LDS, no barriers,
+    // serial folds across lanes).  Measured on MI355X at 9x9 it beats the narrower LDS-fold groups at every batch size
+    // tried (4096 ... 32768 envs: 1.2-1.6x), because a descent is one long dependent chain and what hides its latency
+    // is other waves, not busier lanes.  The narrower groups remain for BL_FORCE_GROUP experiments and for parity tests.
+    int G = 64;
+    (void)B;
     return G;
 }
 

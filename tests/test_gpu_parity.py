@@ -527,3 +527,18 @@ def test_move_rng_serves_one_block_per_move():
     assert (to_np(m.stats.n)[:, 0] == 30).all()
     d = MCTSAgent(net, n_nodes=16, graph=True, rng=MoveRng())(worlds)
     assert worlds.valid.gather(1, d.actions[:, None]).all()
+
+
+@pytest.mark.parametrize('group', [8, 16, 32])
+def test_narrow_group_paths_in_subprocess(group):
+    """The launch heuristic now always picks one wave per env; the 8/16/32-lanes-per-env kernels (LDS fold) stay in the
+    library behind BL_FORCE_GROUP, which is read once per process -- so they are parity-tested in a child process."""
+    import subprocess, sys
+    env = dict(os.environ, BL_FORCE_GROUP=str(group))
+    here = os.path.dirname(os.path.abspath(__file__))
+    r = subprocess.run([sys.executable, '-m', 'pytest', os.path.join(here, 'test_gpu_parity.py'), '-q', '-x', '-m', 'gpu',
+                        '-k', 'test_descend_root_backup_golden and (3x3 or 5x5 or 9x9) and (1- or 37-) or test_random_trees_vs_oracle or '
+                              '(test_full_size_search_vs_oracle and 5-64-16) or (test_whole_search_replay and 5x5)'],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert ' passed' in r.stdout
