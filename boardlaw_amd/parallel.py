@@ -84,3 +84,20 @@ def allreduce_qrange(state):
     dist.all_reduce(wide, op=dist.ReduceOp.MAX)
     state.copy_(torch.where(wide >= 2**31, wide - 2**32, wide).to(torch.int32))
     return state
+
+
+def allreduce_gradients(module):
+    """Averages the module's gradients over ranks with ONE flat all-reduce (RCCL on GPUs).  No-op without a group."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return
+    grads = [p.grad for p in module.parameters() if p.grad is not None]
+    if not grads:
+        return
+    flat = torch.cat([g.reshape(-1).float() for g in grads])
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+    flat /= dist.get_world_size()
+    offset = 0
+    for g in grads:
+        n = g.numel()
+        g.copy_(flat[offset:offset + n].view_as(g))
+        offset += n

@@ -9,14 +9,14 @@ from . import arrdict, heads
 class ProxyAgent:
     """Returns the logits/values the world itself carries."""
 
-    def __call__(self, world, value=False):
+    def __call__(self, world, value=False, eval=False):
         return arrdict.arrdict(logits=world.logits, v=world.v)
 
 
 class RandomAgent:
     """Uniform over valid actions, value 0."""
 
-    def __call__(self, world, value=True):
+    def __call__(self, world, value=True, eval=False):
         valid = world.valid
         return arrdict.arrdict(
             logits=torch.log(valid.float() / valid.sum(-1, keepdims=True)),

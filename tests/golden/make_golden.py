@@ -317,3 +317,7 @@ if __name__ == '__main__':
     gen_search(mcts_mod, hex_, networks, mcuda, out)
     gen_toy(mcts_mod, validation, out)
     gen_exp(out)
+
+
+# tests/golden/learning.npz: produced by calling the reference's boardlaw.learning.reward_to_go / present_value on seeded
+# random buffers (T=16, B=12, S=2); see the snippet in the commit that added it (same import stubs as above).

@@ -542,3 +542,49 @@ def test_narrow_group_paths_in_subprocess(group):
                        env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert ' passed' in r.stdout
+
+
+# ------------------------------------------------------------------------------------------------ widened rows
+@pytest.mark.parametrize('inference,graph', [(None, False), ('fused', True)])
+def test_actor_learner_loop_runs_and_learns_something(inference, graph):
+    """a few actor/learner rounds on 5x5 Hex; the losses are finite and the weights move, also when the
+    actor replays a captured graph with the fused inference plan (weights refreshed inside the graph)."""
+    from boardlaw_amd import hex, networks, training
+    torch.manual_seed(0)
+    worlds = hex.Hex.initial(256, 5, device=DEV)
+    net = networks.FCModel(worlds.obs_space, worlds.action_space, width=128, depth=2).to(DEV)
+    before = torch.cat([p.detach().flatten().clone() for p in net.parameters()])
+    log = []
+    training.run(worlds, net, n_steps=3, nodes=8, buffer_len=4, graph=graph, inference=inference,
+                 on_step=lambda i, pl, vl: log.append((float(pl), float(vl))))
+    after = torch.cat([p.detach().flatten() for p in net.parameters()])
+    assert len(log) == 3 and all(np.isfinite(x).all() for x in log)
+    assert (after - before).abs().max() > 0
+
+
+def test_arena_evaluate_with_search_agents():
+    """arena.common.evaluate with two MCTS agents on Hex -- masked, variable-size batches, argmax actions."""
+    from boardlaw_amd import arena, hex, networks
+    from boardlaw_amd.mcts import MCTSAgent
+    torch.manual_seed(0)
+    worlds = hex.Hex.initial(64, 4, device=DEV)
+    nets = [networks.FCModel(worlds.obs_space, worlds.action_space, width=32, depth=1).to(DEV) for _ in range(2)]
+    agents = {'a': MCTSAgent(nets[0], n_nodes=8), 'b': MCTSAgent(nets[1], n_nodes=8)}
+    results = arena.evaluate(worlds, agents)
+    assert len(results) == 2 and sum(r.games for r in results) == 64
+    assert all(sum(r.wins) == r.games for r in results)
+
+
+def test_ragged_and_tiny_batches():
+    """Variable B as the arena produces it: 1, 3, 65 envs through the whole agent, eager and graphed."""
+    from boardlaw_amd import hex, networks
+    from boardlaw_amd.mcts import MCTSAgent
+    torch.manual_seed(0)
+    net = None
+    for B in (1, 3, 65):
+        worlds = hex.Hex.initial(B, 5, device=DEV)
+        net = net or networks.FCModel(worlds.obs_space, worlds.action_space, width=16, depth=2).to(DEV)
+        for graph in (False, True):
+            d = MCTSAgent(net, n_nodes=8, graph=graph)(worlds, eval=True)
+            assert d.actions.shape == (B,) and worlds.valid.gather(1, d.actions[:, None]).all()
+            assert (d.n_sims == 9).all()

@@ -1,0 +1,130 @@
+"""Actor/learner pieces on CPU: targets against the reference's golden values and known answers, the loss,
+and the 2-rank gradient all-reduce (gloo) against a single-process full-batch step."""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.multiprocessing as mp
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+
+
+def test_reward_to_go_reference_known_answers():
+    """boardlaw/learning.py:83-94"""
+    from boardlaw_amd import learning
+    r, v = torch.tensor([1., 2., 3.]), torch.tensor([4., 5., 6.])
+    out = learning.reward_to_go(r.clone(), v.clone(), torch.tensor([False, False, False]), 1.)
+    assert out.tolist() == [9., 8., 6.]
+    out = learning.reward_to_go(r.clone(), v.clone(), torch.tensor([False, True, False]), 1.)
+    assert out.tolist() == [3., 2., 6.]
+
+
+def test_targets_match_reference_golden():
+    from boardlaw_amd import learning
+    g = np.load(os.path.join(GOLD, 'learning.npz'))
+    reward, value, terminal = (torch.from_numpy(g[k]) for k in ('reward', 'value', 'terminal'))
+    assert np.array_equal(learning.reward_to_go(reward.clone(), value.clone(), terminal, 1.).numpy(), g['reward_to_go'])
+    assert np.array_equal(learning.present_value(reward[:-1], value.clone(), terminal, .9).numpy(), g['present_value_09'])
+
+
+def _toy_batch(n, seed):
+    from boardlaw_amd import arrdict, validation
+    torch.manual_seed(seed)
+    worlds = validation.All.initial(n_envs=n, n_seats=1, length=4, device='cpu')
+    logits = torch.log_softmax(torch.randn(n, 2), -1)
+    return arrdict.arrdict(worlds=worlds, decisions=arrdict.arrdict(logits=logits.half(), v=torch.randn(n, 1).half()),
+                           reward_to_go=torch.randn(n, 1).half())
+
+
+def _toy_net(seed):
+    from boardlaw_amd import networks, heads
+    torch.manual_seed(seed)
+    net = networks.FCModel(heads.Tensor((1,)), heads.Masked(2), width=8, depth=2)
+    with torch.no_grad():
+        for p in net.parameters():
+            if p.ndim == 0:
+                p.fill_(.4)
+    return net
+
+
+def test_losses_formula():
+    """main.py:78-92: -sum(pi0 * log pi) mean + MSE(reward_to_go, v)."""
+    from boardlaw_amd import training
+    net, batch = _toy_net(0), _toy_batch(32, 1)
+    pl, vl = training.losses(net, batch)
+    d = net(batch.worlds)
+    want_pl = -(batch.decisions.logits.float().exp() * d.logits).sum(-1).mean()
+    want_vl = ((batch.reward_to_go - d.v) ** 2).mean()
+    assert torch.allclose(pl, want_pl) and torch.allclose(vl, want_vl)
+
+
+def _free_port():
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _worker(rank, world, port, out):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from boardlaw_amd import parallel, training
+    parallel.init('gloo')
+    net, full = _toy_net(0), _toy_batch(64, 1)
+    shard = full[parallel.shard(64, rank, world)]
+    opt = torch.optim.Adam(net.parameters(), lr=1e-2)
+    scaler = torch.amp.GradScaler('cuda', enabled=False)
+    training.optimize(net, scaler, opt, shard)
+    out.put((rank, torch.cat([p.detach().flatten() for p in net.parameters()]).numpy()))
+    torch.distributed.destroy_process_group()
+
+
+def test_two_rank_gradient_allreduce_equals_full_batch_step():
+    from boardlaw_amd import training
+    world, port = 2, _free_port()
+    ctx = mp.get_context('spawn')
+    out = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, out)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(out.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(60); assert p.exitcode == 0
+    net, full = _toy_net(0), _toy_batch(64, 1)
+    opt = torch.optim.Adam(net.parameters(), lr=1e-2)
+    training.optimize(net, torch.amp.GradScaler('cuda', enabled=False), opt, full, sync_gradients=False)
+    want = torch.cat([p.detach().flatten() for p in net.parameters()]).numpy()
+    assert np.allclose(res[0], res[1], atol=0) and np.allclose(res[0], want, atol=1e-6)
+
+
+def test_as_chunk_shapes():
+    from boardlaw_amd import arrdict, training, validation
+    B, L = 6, 5
+    buf = []
+    worlds = validation.All.initial(n_envs=B, n_seats=1, length=3, device='cpu')
+    for t in range(L):
+        new, trans = worlds.step(torch.ones(B, dtype=torch.long))
+        buf.append(arrdict.arrdict(worlds=worlds, decisions=arrdict.arrdict(v=torch.zeros(B, 1).half(), logits=torch.zeros(B, 2).half()),
+                                   transitions=arrdict.arrdict(terminal=trans.terminal, rewards=trans.rewards.half())))
+        worlds = new
+    chunk, rest = training.as_chunk(buf, B)
+    assert chunk.reward_to_go.shape == (L, B, 1) and chunk.reward_to_go.dtype == torch.half and len(rest) == L - 1
+    # the game ends with +1 on step 3 (length 3, always playing 1): steps 0..2 see reward-to-go 1
+    assert (chunk.reward_to_go[:3].float() == 1).all()
+
+
+def test_arena_evaluate_reference_known_answer():
+    """boardlaw/arena/common.py:108-115 (test_evaluate): on WinnerLoser the first seat always wins."""
+    from boardlaw_amd import arena, validation
+    worlds = validation.WinnerLoser.initial(4, device='cpu')
+    results = arena.evaluate(worlds, {'one': validation.RandomAgent(), 'two': validation.RandomAgent()})
+    assert results[0].wins == (2., 0.) and results[1].wins == (2., 0.)
+    assert results[0].names == ('one', 'two') and results[1].names == ('two', 'one')
+
+
+def test_rollout_on_toy_world():
+    from boardlaw_amd import arena, validation
+    worlds = validation.WinnerLoser.initial(6, device='cpu')
+    trace = arena.rollout(worlds, [validation.RandomAgent(), validation.RandomAgent()], n_steps=4)
+    assert trace.actions.shape == (4, 6) and trace.transitions.terminal.shape == (4, 6)
+    assert trace.transitions.terminal[1::2].all() and not trace.transitions.terminal[0::2].any()
