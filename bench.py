@@ -140,6 +140,14 @@ def main():
         w, _ = w.step(d.actions, check=False)
         return w
 
+    launch = 'eager' if args.eager else 'hip-graph per move'
+    if not args.eager:
+        try:                                   # capture happens on the first call
+            worlds = move(worlds)
+        except Exception as e:                 # pragma: no cover - keep the bench alive if capture is refused
+            print(f'[bench] graph capture failed ({type(e).__name__}: {e}); launching eagerly', file=sys.stderr)
+            torch.cuda.synchronize()
+            agent.graph, args.eager, launch = False, True, f'eager (graph capture failed: {type(e).__name__})'
     for _ in range(args.warmup):
         worlds = move(worlds)
 
@@ -183,7 +191,7 @@ def main():
             'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': f'9x9 Hex, {args.envs} envs/GPU x {NODES} sims/move, FCModel {WIDTH}x{DEPTH} fp16 autocast '
                                    '(BASELINE config 2); step = one self-play move of the batch',
-                       'envs_per_gpu': args.envs, 'nodes': NODES, 'boardsize': BOARD, 'parallelism': f'replicas x{world}', 'launch': 'eager' if args.eager else 'hip-graph per move',
+                       'envs_per_gpu': args.envs, 'nodes': NODES, 'boardsize': BOARD, 'parallelism': f'replicas x{world}', 'launch': launch,
                        'd_policy_evals_per_descent': round(d, 3), 'k_child_lookups_per_descent': round(k, 3),
                        'newton_iters_per_eval': round(its, 3),
                        'bytes_per_sim_whole_path': round(total_bytes_per_sim(A, S, NODES, d, k), 1),
