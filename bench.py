@@ -116,8 +116,11 @@ def main():
     assert torch.cuda.is_available(), 'bench.py needs an MI355X; there is no CPU path'
     from boardlaw_amd import parallel
     rank, world, local = parallel.env_rank()
+    # BENCH_FORCE_DEVICE / BENCH_BACKEND exist only to smoke-test the N>1 code path on a 1-GPU box (two ranks sharing
+    # device 0 over gloo); the driver's multi-GPU runs use one device per rank and RCCL.
+    local = int(os.environ.get('BENCH_FORCE_DEVICE', local))
     torch.cuda.set_device(local)
-    parallel.init('nccl')       # RCCL; used only for the barrier and the max-over-ranks of the elapsed time
+    parallel.init(os.environ.get('BENCH_BACKEND', 'nccl'))   # used only for the barrier and the max-over-ranks of the elapsed time
 
     from boardlaw_amd import _native, networks
     from boardlaw_amd.hex import Hex

@@ -20,14 +20,15 @@ def init(backend=None):
     (rank, world).  World size 1 needs no group."""
     rank, world, local = env_rank()
     if world > 1 and not dist.is_initialized():
+        if torch.cuda.is_available() and 'BENCH_FORCE_DEVICE' not in os.environ:
+            torch.cuda.set_device(local)
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29500')
         if backend is None:
             backend = 'nccl' if torch.cuda.is_available() else 'gloo'
         kwargs = {}
         if backend == 'nccl':
-            torch.cuda.set_device(local)
-            kwargs['device_id'] = torch.device('cuda', local)
+            kwargs['device_id'] = torch.device('cuda', torch.cuda.current_device())
         dist.init_process_group(backend, rank=rank, world_size=world, **kwargs)
     return rank, world
 
