@@ -21,79 +21,74 @@ def matchup_indices(n_envs, n_seats):
     return patterns.repeat((n_envs // len(patterns), 1))
 
 
-def gather(wins, moves, times, matchup_idxs, agents, boardsize):
-    names = np.array([name for name, _ in agents])
-    results = []
-    for p in matchup_patterns(matchup_idxs.shape[1]):
-        sel = (matchup_idxs == p).all(-1)
-        ws = wins[sel].sum(0)
-        results.append(arrdict.dotdict(names=tuple(names[p]), wins=tuple(map(float, ws)), moves=float(moves[sel].sum(0)),
-                                       games=float(ws.sum()), times=float(times[sel].sum(0)), boardsize=boardsize))
-    return results
+def _tally(seat_wins, n_moves, seconds, assignment, names, boardsize):
+    """One record per seat permutation: who sat where, wins per seat, moves, games, wall time."""
+    names = np.array(names)
+    records = []
+    for perm in matchup_patterns(assignment.shape[1]):
+        rows = (assignment == perm).all(-1)
+        w = seat_wins[rows].sum(0)
+        records.append(arrdict.dotdict(names=tuple(names[perm]), wins=tuple(float(x) for x in w), moves=float(n_moves[rows].sum()),
+                                       games=float(w.sum()), times=float(seconds[rows].sum()), boardsize=boardsize))
+    return records
 
 
 def evaluate(worlds, agents):
-    if isinstance(agents, dict):
-        agents = list(agents.items())
-    assert worlds.n_seats == 2, 'Only support 2 seats for now'
-    assert worlds.n_envs % math.factorial(worlds.n_seats) == 0, 'Number of envs needs to be divisible by the number of permutations of seats'
-    assert len(agents) == worlds.n_seats, 'Need to pass one agent per seat'
-    dev, B = worlds.device, worlds.n_envs
-    envs = torch.arange(B, device=dev)
-    terminal = torch.zeros((B,), dtype=torch.bool, device=dev)
-    wins = torch.zeros((B, worlds.n_seats), dtype=torch.int, device=dev)
-    moves = torch.zeros((B,), dtype=torch.int, device=dev)
-    times = torch.zeros((B,), dtype=torch.float, device=dev)
-    matchup_idxs = matchup_indices(B, worlds.n_seats).to(dev)
-    while True:
-        for i, (_, agent) in enumerate(agents):
-            mask = (matchup_idxs[envs, worlds.seats.long()] == i) & ~terminal
-            if mask.any():
-                start = time.time()
-                decisions = agent(worlds[mask], eval=True)
-                worlds[mask], transitions = worlds[mask].step(decisions.actions)
-                terminal[mask] = transitions.terminal
-                end = time.time()
-                wins[mask] += (transitions.rewards == 1).int()
-                moves[mask] += 1
-                times[mask] += (end - start) / mask.sum()
-        if terminal.all():
-            break
-    return gather(wins.cpu(), moves.cpu(), times.cpu(), matchup_idxs.cpu(), agents, getattr(worlds, 'boardsize', None))
+    """Every env plays ONE game; env e seats the agents in the order `assignment[e]` (all seat permutations, tiled over
+    the batch).  A round lets each agent act, with argmax actions, in exactly the unfinished envs where it is to move."""
+    roster = list(agents.items()) if isinstance(agents, dict) else list(agents)
+    n_seats, n_envs, dev = worlds.n_seats, worlds.n_envs, worlds.device
+    assert n_seats == 2, 'Only support 2 seats for now'
+    assert n_envs % math.factorial(n_seats) == 0, 'Number of envs needs to be divisible by the number of permutations of seats'
+    assert len(roster) == n_seats, 'Need to pass one agent per seat'
+    assignment = matchup_indices(n_envs, n_seats).to(dev)
+    everyone = torch.arange(n_envs, device=dev)
+    done = torch.zeros(n_envs, dtype=torch.bool, device=dev)
+    seat_wins = torch.zeros((n_envs, n_seats), dtype=torch.int, device=dev)
+    n_moves = torch.zeros(n_envs, dtype=torch.int, device=dev)
+    seconds = torch.zeros(n_envs, dtype=torch.float, device=dev)
+    while not bool(done.all()):
+        for who, (_, agent) in enumerate(roster):
+            to_move = (assignment[everyone, worlds.seats.long()] == who) & ~done
+            if not bool(to_move.any()):
+                continue
+            t0 = time.time()
+            picks = agent(worlds[to_move], eval=True).actions
+            worlds[to_move], outcome = worlds[to_move].step(picks)
+            done[to_move] = outcome.terminal
+            elapsed = time.time() - t0
+            seat_wins[to_move] += (outcome.rewards == 1).int()
+            n_moves[to_move] += 1
+            seconds[to_move] += elapsed / to_move.sum()
+    return _tally(seat_wins.cpu(), n_moves.cpu(), seconds.cpu(), assignment.cpu(), [name for name, _ in roster],
+                  getattr(worlds, 'boardsize', None))
 
 
-def combine_actions(decisions, masks):
-    actions = torch.cat([d.actions for d in decisions.values()])
-    for mask, decision in zip(masks.values(), decisions.values()):
-        actions[mask] = decision.actions
-    return actions
+def _merge_actions(per_seat, masks):
+    merged = torch.cat([d.actions for d in per_seat.values()])
+    for seat, d in per_seat.items():
+        merged[masks[seat]] = d.actions
+    return merged
 
 
 @torch.no_grad()
 def rollout(worlds, agents, n_steps=None, n_trajs=None, n_reps=None, **kwargs):
-    """Plays the agents against each other by seat and records the trace (boardlaw/analysis.py:47-87):
+    """Self-play trace (the role of boardlaw/analysis.py:47-87): agent i acts wherever seat i is to move; stops after
+    n_steps steps, n_trajs finished games in total, or n_reps finished games in every env.  Returns
     arrdict(actions, transitions, worlds) stacked over time."""
-    assert sum(x is not None for x in (n_steps, n_trajs, n_reps)) == 1, 'Must specify exactly one of n_steps or n_trajs or n_reps'
-    trace = []
-    steps, trajs = 0, 0
-    reps = torch.zeros(worlds.n_envs, device=worlds.device)
+    if sum(x is not None for x in (n_steps, n_trajs, n_reps)) != 1:
+        raise AssertionError('Must specify exactly one of n_steps or n_trajs or n_reps')
+    frames, finished, per_env = [], 0, torch.zeros(worlds.n_envs, device=worlds.device)
     while True:
-        decisions, masks = {}, {}
-        for i, agent in enumerate(agents):
-            mask = worlds.seats == i
-            if mask.any():
-                decisions[i] = agent(worlds[mask], **kwargs)
-                masks[i] = mask
-        actions = combine_actions(decisions, masks)
+        per_seat, masks = {}, {}
+        for seat, agent in enumerate(agents):
+            here = worlds.seats == seat
+            if bool(here.any()):
+                per_seat[seat], masks[seat] = agent(worlds[here], **kwargs), here
+        actions = _merge_actions(per_seat, masks)
         worlds, transitions = worlds.step(actions)
-        trace.append(arrdict.arrdict(actions=actions, transitions=transitions, worlds=worlds))
-        steps += 1
-        if n_steps and steps >= n_steps:
-            break
-        trajs += transitions.terminal.sum()
-        if n_trajs and trajs >= n_trajs:
-            break
-        reps += transitions.terminal
-        if n_reps and (reps >= n_reps).all():
-            break
-    return arrdict.stack(trace)
+        frames.append(arrdict.arrdict(actions=actions, transitions=transitions, worlds=worlds))
+        finished += int(transitions.terminal.sum())
+        per_env += transitions.terminal
+        if (n_steps and len(frames) >= n_steps) or (n_trajs and finished >= n_trajs) or (n_reps and bool((per_env >= n_reps).all())):
+            return arrdict.stack(frames)
