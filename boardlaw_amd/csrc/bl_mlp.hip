@@ -132,8 +132,9 @@ __global__ void __launch_bounds__(WAVES * 64) mlp_kernel(Params p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int W = p.W, ld = W + 8;                  // +8 halves: rows 16 B apart in bank space, ds_read_b128 conflict-free
     uint16_t* X = (uint16_t*)smem;                  // residual stream, f16 [32][ld]
-    uint16_t* Rbuf[2] = {X + 32 * ld, X + 64 * ld}; // relu(X) / staged input, double-buffered: a layer's epilogue writes
-                                                    // the buffer the NEXT layer reads, so one barrier per layer suffices
+    // relu(X) / staged input, double-buffered at X + 32*ld*(1 + parity): a layer's epilogue writes the buffer the NEXT
+    // layer reads, so one barrier per layer suffices.  (Offsets from the one LDS base, not an array of pointers: the
+    // latter decays to generic pointers and turns every LDS access into a flat_load/flat_store.)
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int row0 = blockIdx.x * 32;
     const int n0 = wave * 32 * NT, tile0 = wave * NT;
@@ -143,12 +144,16 @@ __global__ void __launch_bounds__(WAVES * 64) mlp_kernel(Params p) {
     CLK(0)
     float16v acc[NT];
     Ring<NT> rg;
-    Ring<1> hr;
     gemm_prefetch<NT>(rg, p.w0, p.K0pad, tile0, NT);          // weights first: their latency hides behind the staging
-    // stage the observation tile (rows are contiguous in global memory), zero-padding K0 -> K0pad and rows >= M
-    for (int r = tid >> 4; r < 32; r += NTHREADS / 16)
-        for (int k = tid & 15; k < p.K0pad; k += 16)
-            Rbuf[0][r * ld + k] = (k < p.K0 && row0 + r < p.M) ? p.obs[(long)(row0 + r) * p.K0 + k] : (uint16_t)0;
+    // stage the observation tile as 32-bit words (K0 is even: 2 planes per cell), zero-padding K0 -> K0pad and rows >= M
+    {
+        const int wpr = p.K0pad >> 1, wvalid = p.K0 >> 1;           // words per staged row / per real row
+        const uint32_t* src = (const uint32_t*)p.obs;               // row r starts at word r * K0 / 2 (K0 even)
+        uint32_t* dst = (uint32_t*)(X + 32 * ld);
+        for (int r = tid >> 5; r < 32; r += NTHREADS / 32)
+            for (int w = tid & 31; w < wpr; w += 32)
+                dst[r * (ld >> 1) + w] = (w < wvalid && row0 + r < p.M) ? src[(long)(row0 + r) * wvalid + w] : 0u;
+    }
     __syncthreads();
     CLK(1)
 
@@ -159,13 +164,12 @@ __global__ void __launch_bounds__(WAVES * 64) mlp_kernel(Params p) {
         uint2 biasr[NT][4];                                       // issued now, needed after the GEMM
 #pragma unroll
         for (int t = 0; t < NT; t++) for (int g = 0; g < 4; g++) biasr[t][g] = *(const uint2*)(bl + n0 + 32 * t + 8 * g + 4 * hf);
-        gemm_run<NT>(rg, Rbuf[l & 1], ld, Wl, l == 0 ? p.K0pad : W, tile0, NT, acc);
+        gemm_run<NT>(rg, X + 32 * ld * (1 + (l & 1)), ld, Wl, l == 0 ? p.K0pad : W, tile0, NT, acc);
         CLK(2 + 3 * l)
         if (l < p.D) gemm_prefetch<NT>(rg, p.wb + (long)l * W * W, W, tile0, NT);
-        else if (wave < p.NHpad / 32) gemm_prefetch<1>(hr, p.wh, W, wave, 1);
         half2v al2 = {(f16)0.f, (f16)0.f};
         if (l > 0) { const f16 a = (f16)p.alphas[l - 1]; al2[0] = a; al2[1] = a; }   // torch casts the f32 0-dim parameter to f16
-        uint16_t* Rn = Rbuf[(l + 1) & 1];
+        uint16_t* Rn = X + 32 * ld * (1 + ((l + 1) & 1));
 #pragma unroll
         for (int t = 0; t < NT; t++) {
 #pragma unroll
@@ -184,23 +188,71 @@ __global__ void __launch_bounds__(WAVES * 64) mlp_kernel(Params p) {
         __syncthreads();
         CLK(4 + 3 * l)
     }
-    // heads' Linears on the un-rectified neck: one 32-feature tile per wave (3 tiles for 9x9), weights already in flight
-    const int htiles = p.NHpad / 32;
-    for (int t0 = wave; t0 < htiles; t0 += WAVES) {
-        float16v hacc[1];
-        if (t0 != wave) gemm_prefetch<1>(hr, p.wh, W, t0, 1);
-        gemm_run<1>(hr, X, ld, p.wh, W, t0, 1, hacc);
-        const int r = row0 + brow;
-        if (r < p.M) {
+    // heads' Linears on the un-rectified neck.  The NHpad/32 output tiles are few (3 for 9x9), so each tile's K range is
+    // split over two waves (waves 2t and 2t+1); the upper half's partial sums go through LDS (the relu buffers are free
+    // now) to the lower half's wave, which adds them in a fixed order and stores.
+    const int htiles = p.NHpad / 32, KBh = W >> 6;
+    float* Part = (float*)(X + 32 * ld);                          // [unit][16][64] f32, 4 KiB per unit
+    for (int round = 0; round * WAVES < 2 * htiles; round++) {    // same trip count for every wave: uniform barriers
+        const int u = round * WAVES + wave;
+        const bool active = u < 2 * htiles;
+        const int t0 = active ? (u >> 1) : 0, khalf = u & 1;
+        const int kb0 = khalf ? KBh / 2 : 0, kb1 = khalf ? KBh : KBh / 2;
+        float16v hacc;
+        for (int i = 0; i < 16; i++) hacc[i] = 0.f;
+        if (active) {
+            const uint16_t* arow = X + brow * ld + 32 * hf;
+            const uint16_t* bt = p.wh + (long)t0 * KBh * 2048 + lane * 8;
+            auto loadb = [&](half8 (&b)[4], int kb) {
 #pragma unroll
-            for (int i = 0; i < 16; i++) {
-                const int f = 32 * t0 + (i & 3) + 8 * (i >> 2) + 4 * hf;
-                if (f < p.NH) {
-                    const uint16_t o = f2h(hacc[0][i] + h2f(p.bh[f]));
-                    if (f < p.NH - 1) p.policy[(long)r * (p.NH - 1) + f] = o; else p.value[r] = o;
+                for (int s2 = 0; s2 < 4; s2++) b[s2] = *(const half8*)(bt + kb * 2048 + s2 * 512);
+            };
+            auto step = [&](half8 (&b)[4], int kb) {
+                half8 a[4];
+#pragma unroll
+                for (int s2 = 0; s2 < 4; s2++) a[s2] = *(const half8*)(arow + kb * 64 + 8 * s2);
+#pragma unroll
+                for (int s2 = 0; s2 < 4; s2++) hacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(b[s2], a[s2], hacc, 0, 0, 0);
+            };
+            half8 be[4], bo[4];                                   // two k blocks in flight, alternating
+            loadb(be, kb0);
+            for (int kb = kb0; kb < kb1; kb += 2) {
+                if (kb + 1 < kb1) loadb(bo, kb + 1);
+                step(be, kb);
+                if (kb + 1 < kb1) {
+                    if (kb + 2 < kb1) loadb(be, kb + 2);
+                    step(bo, kb + 1);
                 }
             }
         }
+        __syncthreads();                                          // every wave has finished reading the relu buffers' owner X
+        if (active && khalf == 1) {
+#pragma unroll
+            for (int i = 0; i < 16; i++) Part[(t0 * 16 + i) * 64 + lane] = hacc[i];
+        }
+        __syncthreads();
+        uint16_t* Out = (uint16_t*)(Part + htiles * 16 * 64);      // [32 rows][NHpad] f16 staging for coalesced stores
+        if (active && khalf == 0) {
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                const int f0 = 32 * t0 + 8 * g + 4 * hf;              // 4 consecutive output features of row `brow`
+                uint16_t o[4];
+#pragma unroll
+                for (int j = 0; j < 4; j++) o[j] = f2h(hacc[4 * g + j] + Part[(t0 * 16 + 4 * g + j) * 64 + lane] + h2f(p.bh[f0 + j]));
+                *(uint2*)(Out + brow * p.NHpad + f0) = make_uint2(o[0] | ((uint32_t)o[1] << 16), o[2] | ((uint32_t)o[3] << 16));
+            }
+        }
+        __syncthreads();
+    }
+    // coalesced stores: a wave writes one row's NH-1 policy outputs as consecutive halves
+    {
+        const uint16_t* Out = (const uint16_t*)(Part + htiles * 16 * 64);
+        for (int r = wave; r < 32; r += WAVES) {
+            if (row0 + r < p.M) {
+                for (int f = lane; f < p.NH - 1; f += 64) p.policy[(long)(row0 + r) * (p.NH - 1) + f] = Out[r * p.NHpad + f];
+            }
+        }
+        if (tid < 32 && row0 + tid < p.M) p.value[row0 + tid] = Out[tid * p.NHpad + p.NH - 1];
     }
     CLK(40)
 }
@@ -219,8 +271,10 @@ extern "C" int bl_mlp_forward_f16(const void* obs, int M, int K0, const void* w0
     if (W % 128 != 0 || W < 128 || W > 1024 || K0pad % 64 != 0 || K0pad < K0 || K0pad > W || NHpad % 32 != 0 || NHpad < NH) return BL_ETOOBIG;
     Params p{(const uint16_t*)obs, (const uint16_t*)w0, (const uint16_t*)b0, (const uint16_t*)wb, (const uint16_t*)bb, alphas,
              (const uint16_t*)wh, (const uint16_t*)bh, (uint16_t*)policy_out, (uint16_t*)value_out, M, K0, K0pad, W, D, NH, NHpad};
-    // X + two R buffers
-    const size_t lds = (size_t)3 * 32 * (W + 8) * 2;
+    // X + two R buffers; the heads reuse the R region for split-K partials and the output staging
+    size_t lds = (size_t)3 * 32 * (W + 8) * 2;
+    const size_t lds_heads = (size_t)32 * (W + 8) * 2 + (size_t)(NHpad / 32) * 16 * 64 * 4 + (size_t)32 * NHpad * 2;
+    if (lds_heads > lds) lds = lds_heads;
     if (lds > 160 * 1024) return BL_ETOOBIG;
     const dim3 grid((M + 31) / 32);
     hipStream_t hs = (hipStream_t)stream;
