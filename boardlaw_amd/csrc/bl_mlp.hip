@@ -157,7 +157,12 @@ __global__ void __launch_bounds__(WAVES * 64) mlp_kernel(Params p) {
     __syncthreads();
     CLK(1)
 
-    // intake Linear, then the ReZero blocks (networks.py:17-18): layer l reads Rbuf[l & 1], writes Rbuf[(l + 1) & 1]
+    // intake Linear, then the ReZero blocks (networks.py:17-18): layer l reads relu buffer (l & 1), writes ((l + 1) & 1).
+    // A wave owns the same columns of the same rows in every layer, so its slice of the residual stream x stays in
+    // registers (packed f16) from layer to layer; only relu(x) -- the next GEMM's input -- goes through LDS.
+    uint2 xreg[NT][4];
+#pragma unroll
+    for (int t = 0; t < NT; t++) for (int g = 0; g < 4; g++) xreg[t][g] = make_uint2(0, 0);
     for (int l = 0; l <= p.D; l++) {
         const uint16_t* Wl = l == 0 ? p.w0 : p.wb + (long)(l - 1) * W * W;
         const uint16_t* bl = l == 0 ? p.b0 : p.bb + (long)(l - 1) * W;
@@ -176,11 +181,12 @@ __global__ void __launch_bounds__(WAVES * 64) mlp_kernel(Params p) {
             for (int g = 0; g < 4; g++) {
                 const int f0 = n0 + 32 * t + 8 * g + 4 * hf;             // 4 consecutive features of batch row `brow`
                 const uint2 bias = biasr[t][g];
-                const uint2 xold = l > 0 ? *(const uint2*)(X + brow * ld + f0) : make_uint2(0, 0);
+                const uint2 xold = xreg[t][g];
                 const float a4[4] = {acc[t][4 * g], acc[t][4 * g + 1], acc[t][4 * g + 2], acc[t][4 * g + 3]};
                 uint2 xo, ro;
                 rezero4(a4, bias, xold, al2, l == 0, xo, ro);
-                *(uint2*)(X + brow * ld + f0) = xo;
+                xreg[t][g] = xo;
+                if (l == p.D) *(uint2*)(X + brow * ld + f0) = xo;     // only the heads read the neck from LDS
                 *(uint2*)(Rn + brow * ld + f0) = ro;
             }
         }
