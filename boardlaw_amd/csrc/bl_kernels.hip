@@ -298,6 +298,10 @@ __device__ __forceinline__ float readlane_f(float v, int lane) {
 #define BL_FOLD8(x, y, ts, tg)                                                                              \
     asm volatile("s_nop 1\n\t" BL_FOLD_STEP BL_FOLD_STEP BL_FOLD_STEP BL_FOLD_STEP BL_FOLD_STEP BL_FOLD_STEP \
                  BL_FOLD_STEP BL_FOLD_STEP : "+v"(x), "+v"(y) : "v"(ts), "v"(tg))
+#define BL_FOLD16(x, y, ts, tg)                                                                             \
+    asm volatile("s_nop 1\n\t" BL_FOLD_STEP BL_FOLD_STEP BL_FOLD_STEP BL_FOLD_STEP BL_FOLD_STEP BL_FOLD_STEP \
+                 BL_FOLD_STEP BL_FOLD_STEP BL_FOLD_STEP BL_FOLD_STEP BL_FOLD_STEP BL_FOLD_STEP BL_FOLD_STEP     \
+                 BL_FOLD_STEP BL_FOLD_STEP BL_FOLD_STEP : "+v"(x), "+v"(y) : "v"(ts), "v"(tg))
 
 template <int K, bool COUNT, bool WANT_PROB>
 __device__ __forceinline__ int policy_eval_wave(const Tree& m, int b, int t, int seat, float lo, float rden, float r,
@@ -406,7 +410,9 @@ __device__ __forceinline__ int policy_eval_wave(const Tree& m, int b, int t, int
                 float x = cprob[k], y = tg[k];
                 if (lane == 0) { x = cs + x; y = cg + y; }
                 const int steps = (k == last_k) ? last_lane : 63;
-                for (int j = 0; j < steps; j += 8) BL_FOLD8(x, y, cprob[k], tg[k]);
+                int j = 0;
+                for (; j + 8 < steps; j += 16) BL_FOLD16(x, y, cprob[k], tg[k]);     // extra steps past `steps` are harmless
+                for (; j < steps; j += 8) BL_FOLD8(x, y, cprob[k], tg[k]);
                 tot[k] = x;
                 if (k == last_k) { Ssum = readlane_f(x, last_lane); gsum_ = readlane_f(y, last_lane); }
                 else { cs = readlane_f(x, 63); cg = readlane_f(y, 63); }
