@@ -276,8 +276,8 @@ def mcts(worlds, network, **kwargs):
     m = MCTS(worlds, **kwargs)
     if hasattr(m.rng, 'start') and m.n_nodes > 1:
         m.rng.start(m.n_nodes - 1, m.decisions.logits[:, :, 0])
-    if hasattr(network, 'refresh'):
-        network.refresh()          # once per search: picks up optimiser steps, and is part of the captured move
+    if hasattr(network, 'refresh_if_stale') and not (worlds.device.type == 'cuda' and torch.cuda.is_current_stream_capturing()):
+        network.refresh_if_stale()     # picks up optimiser steps; a captured move is refreshed by its replayer instead
     m.initialize(network)
     for _ in range(m.n_nodes - 1):
         m.simulate(network)
@@ -337,7 +337,10 @@ class _GraphedMove:
     def __init__(self, agent, world, eval):
         dev = world.device
         self.board, self.seats = world.board.clone(), world.seats.clone()
+        self.network = agent.network
         kind = type(world)
+        if hasattr(self.network, 'refresh_if_stale'):
+            self.network.refresh_if_stale()
 
         def run():
             return agent._move(kind(board=self.board, seats=self.seats), eval, {})
@@ -354,6 +357,8 @@ class _GraphedMove:
 
     def __call__(self, world):
         self.board.copy_(world.board); self.seats.copy_(world.seats)
+        if hasattr(self.network, 'refresh_if_stale'):
+            self.network.refresh_if_stale()    # in place, outside the graph: replays read the static f16 weight buffers
         self.graph.replay()
         return self.out.clone()
 

@@ -70,6 +70,7 @@ class Inference:
         self.fused = fused
         self._static = None
         self._packed = None
+        self._stamped = None
 
     def __call__(self, worlds):
         return self.model(worlds)
@@ -98,6 +99,16 @@ class Inference:
         W, K0 = blocks[0].weight.shape
         return (W % 128 == 0 and 128 <= W <= 512 and -(-K0 // 64) * 64 <= W and type(m.policy).__name__ in ('MaskedOutput', 'DiscreteOutput')
                 and blocks[0].weight.is_cuda)
+
+    def _stamp(self):
+        srcs, alphas = self._sources()
+        return tuple((p.data_ptr(), p._version) for p in list(srcs) + list(alphas))
+
+    def refresh_if_stale(self):
+        """refresh() only if a parameter was modified in place (optimiser step, load_state_dict) or replaced since the
+        last refresh.  Host-side check of tensor version counters: no device work when nothing changed."""
+        if self._static is None or self._stamp() != self._stamped:
+            self.refresh()
 
     def refresh(self):
         """Re-cast the module's current parameters into the static f16 buffers (in place: safe to capture/replay)."""
@@ -132,6 +143,7 @@ class Inference:
                 stageh[:A] = w[-4]; stageh[A] = w[-2][0]
                 pk['wh'].view(-1).copy_(pack_fragment_major(stageh).view(-1))
                 pk['bh'][:A].copy_(w[-3]); pk['bh'][A].copy_(w[-1][0])
+        self._stamped = self._stamp()
 
     def raw(self, worlds):
         from . import _native
