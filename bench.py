@@ -139,9 +139,8 @@ def main():
     lib.bl_sim_expand = timer
 
     def move(w):
-        d = agent(w)
-        w, _ = w.step(d.actions, check=False)
-        return w
+        # one actor step of the self-play loop (boardlaw/main.py:176-177): search + env step
+        return agent.play(w)[1]
 
     launch = 'eager' if args.eager else 'hip-graph per move'
     if not args.eager:
@@ -175,7 +174,7 @@ def main():
             probe = MCTSAgent(agent.network, n_nodes=NODES, graph=False, rng=MoveRng())
             timer.on = True
             for _ in range(min(args.steps, 5)):
-                worlds, _ = worlds.step(probe(worlds).actions, check=False)
+                worlds = probe.play(worlds)[1]
             torch.cuda.synchronize()
             timer.on = False
         lib.bl_sim_expand = timer.orig

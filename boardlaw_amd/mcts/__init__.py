@@ -268,7 +268,14 @@ class MCTS:
             v=self.decisions.v[:, 0])
 
     def n_leaves(self):
-        return ((self.tree.children == -1).all(-1) & (self.tree.parents != -1)).sum(-1)
+        """Nodes that exist and have no child (mcts/__init__.py:151-152: `(children == -1).all(-1) & (parents != -1)`).
+        A node has a child exactly when some node names it as its parent, so this reads the two (B,T) arrays instead of
+        the (B,T,A) children array (42 MB at 9x9/4096/64)."""
+        parents = self.tree.parents
+        exists = parents != -1
+        n_children = torch.zeros(parents.shape, dtype=torch.int32, device=parents.device)
+        n_children.scatter_add_(1, parents.clamp(min=0).long(), exists.int())   # += 1 at parents[b,t] for every existing t
+        return (exists & (n_children == 0)).sum(-1)
 
 
 def mcts(worlds, network, **kwargs):
@@ -319,6 +326,20 @@ class MCTSAgent:
             self._graphs[key] = _GraphedMove(self, world, eval)
         return self._graphs[key](world)
 
+    def play(self, world, eval=False):
+        """One actor step of the self-play loop (boardlaw/main.py:176-177): decisions = agent(world); new_world,
+        transition = world.step(decisions.actions).  With graph=True both halves replay as ONE captured graph (the env
+        step's validity asserts -- host syncs -- are skipped: the search only ever draws legal actions).
+        Returns (decisions, new_world, transition)."""
+        if not self.graph or world.device.type != 'cuda':
+            d = self._move(world, eval, {})
+            new_world, transition = world.step(d.actions)
+            return d, new_world, transition
+        key = ('play', type(world), world.n_envs, world.boardsize, bool(eval), world.device)
+        if key not in self._graphs:
+            self._graphs[key] = _GraphedMove(self, world, eval, step=True)
+        return self._graphs[key](world)
+
     def load_state_dict(self, sd):
         self.network.load_state_dict({k[len('network.'):]: v for k, v in sd.items() if k.startswith('network.')})
         self.kwargs.update({k[len('kwargs.'):]: v for k, v in sd.items() if k.startswith('kwargs.')})
@@ -334,16 +355,22 @@ class _GraphedMove:
     graph is replayed, outputs are cloned out.  Network parameters are read in place, so training steps between
     replays are seen."""
 
-    def __init__(self, agent, world, eval):
+    def __init__(self, agent, world, eval, step=False):
         dev = world.device
         self.board, self.seats = world.board.clone(), world.seats.clone()
         self.network = agent.network
+        self.step = step
         kind = type(world)
         if hasattr(self.network, 'refresh_if_stale'):
             self.network.refresh_if_stale()
 
         def run():
-            return agent._move(kind(board=self.board, seats=self.seats), eval, {})
+            w = kind(board=self.board, seats=self.seats)
+            d = agent._move(w, eval, {})
+            if not step:
+                return d
+            new_world, transition = w.step(d.actions, check=False)
+            return d, arrdict.arrdict(board=new_world.board, seats=new_world.seats), transition
 
         with torch.cuda.device(dev):
             side = torch.cuda.Stream()
@@ -354,13 +381,18 @@ class _GraphedMove:
             self.graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.graph):
                 self.out = run()
+        self.kind = kind
 
     def __call__(self, world):
         self.board.copy_(world.board); self.seats.copy_(world.seats)
         if hasattr(self.network, 'refresh_if_stale'):
             self.network.refresh_if_stale()    # in place, outside the graph: replays read the static f16 weight buffers
         self.graph.replay()
-        return self.out.clone()
+        if not self.step:
+            return self.out.clone()
+        d, w, t = self.out
+        w = w.clone()
+        return d.clone(), self.kind(board=w.board, seats=w.seats), t.clone()
 
 
 class DummyAgent:

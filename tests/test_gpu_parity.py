@@ -588,3 +588,24 @@ def test_ragged_and_tiny_batches():
             d = MCTSAgent(net, n_nodes=8, graph=graph)(worlds, eval=True)
             assert d.actions.shape == (B,) and worlds.valid.gather(1, d.actions[:, None]).all()
             assert (d.n_sims == 9).all()
+
+
+def test_graphed_play_equals_eager_play():
+    """MCTSAgent.play (search + env step) replayed as one graph == the two eager calls, for the same generator state."""
+    from boardlaw_amd import hex, networks
+    from boardlaw_amd.mcts import MCTSAgent
+    torch.manual_seed(0)
+    worlds = hex.Hex.initial(128, 4, device=DEV)
+    net = networks.FCModel(worlds.obs_space, worlds.action_space, width=32, depth=2).to(DEV)
+    eager, graphed = MCTSAgent(net, n_nodes=12), MCTSAgent(net, n_nodes=12, graph=True)
+    graphed.play(worlds)
+    for move in range(12):                  # long enough for 4x4 games to end and reset
+        state = torch.cuda.get_rng_state()
+        d0, w0, t0 = eager.play(worlds)
+        torch.cuda.set_rng_state(state)
+        d1, w1, t1 = graphed.play(worlds)
+        assert torch.equal(d0.actions, d1.actions) and torch.equal(d0.logits, d1.logits)
+        assert torch.equal(w0.board, w1.board) and torch.equal(w0.seats, w1.seats)
+        assert torch.equal(t0.terminal, t1.terminal) and torch.equal(t0.rewards, t1.rewards)
+        worlds = w1
+    assert isinstance(worlds, hex.Hex)
