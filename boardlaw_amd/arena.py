@@ -64,31 +64,4 @@ def evaluate(worlds, agents):
                   getattr(worlds, 'boardsize', None))
 
 
-def _merge_actions(per_seat, masks):
-    merged = torch.cat([d.actions for d in per_seat.values()])
-    for seat, d in per_seat.items():
-        merged[masks[seat]] = d.actions
-    return merged
-
-
-@torch.no_grad()
-def rollout(worlds, agents, n_steps=None, n_trajs=None, n_reps=None, **kwargs):
-    """Self-play trace (the role of boardlaw/analysis.py:47-87): agent i acts wherever seat i is to move; stops after
-    n_steps steps, n_trajs finished games in total, or n_reps finished games in every env.  Returns
-    arrdict(actions, transitions, worlds) stacked over time."""
-    if sum(x is not None for x in (n_steps, n_trajs, n_reps)) != 1:
-        raise AssertionError('Must specify exactly one of n_steps or n_trajs or n_reps')
-    frames, finished, per_env = [], 0, torch.zeros(worlds.n_envs, device=worlds.device)
-    while True:
-        per_seat, masks = {}, {}
-        for seat, agent in enumerate(agents):
-            here = worlds.seats == seat
-            if bool(here.any()):
-                per_seat[seat], masks[seat] = agent(worlds[here], **kwargs), here
-        actions = _merge_actions(per_seat, masks)
-        worlds, transitions = worlds.step(actions)
-        frames.append(arrdict.arrdict(actions=actions, transitions=transitions, worlds=worlds))
-        finished += int(transitions.terminal.sum())
-        per_env += transitions.terminal
-        if (n_steps and len(frames) >= n_steps) or (n_trajs and finished >= n_trajs) or (n_reps and bool((per_env >= n_reps).all())):
-            return arrdict.stack(frames)
+from .analysis import rollout  # noqa: E402,F401  (kept here for callers that imported it from arena)

@@ -323,6 +323,8 @@ __device__ __forceinline__ int policy_eval_wave(const Tree& m, int b, int t, int
         child[k] = -1; lb[k] = 0; info[k] = 0;
         if (a < A) { child[k] = m.children[row + a]; lb[k] = m.logits[row + a]; }
     }
+    long long trt1 = 0, tq = 0;
+    if (COUNT) { __builtin_amdgcn_s_waitcnt(0); trt1 = clock64() - tp0; }     // rows of the node have landed
 #pragma unroll
     for (int k = 0; k < K; k++) {
         const int a = k * 64 + lane;
@@ -344,6 +346,7 @@ __device__ __forceinline__ int policy_eval_wave(const Tree& m, int b, int t, int
         }
         top[k] = pi; q[k] = qa; prob[k] = 0.f; tg[k] = 0.f;
     }
+    if (COUNT) { __builtin_amdgcn_s_waitcnt(0); tq = clock64() - tp0; }       // + children's statistics and q
     const int N = wave_sum_i32(Nloc);
     const float lam = (h2f(m.c_puct[b]) * (float)N) / (float)(unsigned)(N + A);
     float alpha = 0.f;
@@ -468,7 +471,7 @@ __device__ __forceinline__ int policy_eval_wave(const Tree& m, int b, int t, int
         if (lane == 0) {
             unsigned long long* e = counters + 12 * (long)b;
             e[0] += 1; e[1] += iters; if ((unsigned long long)iters > e[2]) e[2] = iters; e[3] += nc;
-            e[4] += tload; e[5] += tdiv; e[6] += tfold; e[7] += tupd;
+            e[4] += tload; e[5] += tdiv; e[6] += tfold; e[7] += tupd; e[10] += trt1; e[11] += tq;
         }
     }
     return action;

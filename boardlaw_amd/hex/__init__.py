@@ -71,6 +71,55 @@ class Hex(arrdict.namedarrtuple('Hex', fields=('board', 'seats'))):
         return type(self)(board=new_board, seats=new_seats), arrdict.arrdict(terminal=terminal, rewards=rewards)
 
 
+class Solitaire(Hex):
+    """One-player Hex (hex/__init__.py:224-255): seat 0 is the player; after its move a scripted opponent (`_play`)
+    answers in every env where it is now seat 1's turn, and the player sees the summed transition for its own seat
+    only -- rewards (B,1)."""
+
+    @classmethod
+    def initial(cls, *args, seat=0, **kwargs):
+        if seat == 1:
+            raise ValueError('Can\'t do seat #1 right now')
+        return super().initial(*args, **kwargs)
+
+    def __init__(self, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        if isinstance(self['board'], torch.Tensor):
+            self.n_seats = 1
+
+    def step(self, actions, **kwargs):
+        worlds, transitions = super().step(actions, **kwargs)
+        # a winning move resets the env to seat 0 already; everywhere else the opponent answers until the player is
+        # to move again (one answer, unless that answer itself ends the game -- then the reset hands the move back)
+        while True:
+            theirs = worlds.seats != self.seats
+            if not bool(theirs.any()):
+                break
+            worlds[theirs], reply = self._play(worlds[theirs])
+            transitions.rewards[theirs] += reply.rewards
+            transitions.terminal[theirs] |= reply.terminal
+        mine = self.seats.long()[:, None]
+        transitions['rewards'] = transitions.rewards.gather(1, mine)
+        return worlds, transitions
+
+
+class Lazy(Solitaire):
+    """Opponent plays the first available cell (hex/__init__.py:257-266)."""
+
+    @classmethod
+    def _play(cls, worlds):
+        first = worlds.valid.int().argmax(-1)       # lowest index with valid == True
+        return Hex.step(worlds, first)
+
+
+class Random(Solitaire):
+    """Opponent plays a uniformly random available cell (hex/__init__.py:268-274)."""
+
+    @classmethod
+    def _play(cls, worlds):
+        return Hex.step(worlds, torch.distributions.Categorical(probs=worlds.valid.float()).sample())
+
+
 def board_actions(s):
     """Move list that reproduces a board drawn with `b`/`w`/`.` rows (boardlaw/hex/tests.py:101-122)."""
     rows = [l.strip() for l in s.splitlines() if l.strip()]

@@ -103,7 +103,8 @@ class MCTS:
         # optional callable(state_row) run after every backup on the q-range row the next descent will read, e.g.
         # parallel.allreduce_qrange: env shards on several GPUs then normalise q over ALL envs like one big batch
         self.qrange_sync = qrange_sync
-        self.fused = isinstance(world, hexmod.Hex) if fused is None else fused
+        # the fused kernels hard-code two-seat Hex; its one-player variants (hex.Solitaire) take the generic path
+        self.fused = (isinstance(world, hexmod.Hex) and world.n_seats == 2) if fused is None else fused
         if self.fused and not isinstance(world, hexmod.Hex):
             raise ValueError('The fused path is Hex-only')
         B, T, A, S, dev = self.n_envs, n_nodes, self.n_actions, self.n_seats, self.device

@@ -609,3 +609,43 @@ def test_graphed_play_equals_eager_play():
         assert torch.equal(t0.terminal, t1.terminal) and torch.equal(t0.rewards, t1.rewards)
         worlds = w1
     assert isinstance(worlds, hex.Hex)
+
+
+def test_one_player_hex_variants():
+    """hex.Solitaire/Lazy/Random (hex/__init__.py:224-274): the player is always seat 0, the scripted
+    opponent answers inside step(), rewards are the player's column only."""
+    from boardlaw_amd import hex, validation
+    from boardlaw_amd.mcts import mcts
+    with pytest.raises(ValueError):
+        hex.Lazy.initial(2, 3, seat=1, device=DEV)
+    w = hex.Lazy.initial(4, 3, device=DEV)
+    assert w.n_seats == 1
+    w2, tr = w.step(torch.full((4,), 4, device=DEV))
+    assert type(w2) is hex.Lazy and (w2.seats == 0).all() and tr.rewards.shape == (4, 1) and not tr.terminal.any()
+    # black in the centre; white answered at ITS first free cell = index 0 of the transposed frame = (0,0), a left-edge cell
+    assert (w2.board[:, 1, 1] == 1).all() and (w2.board[:, 0, 0] == 5).all() and (w2.board != 0).sum() == 8
+    # same position reached with plain two-player Hex
+    h = hex.Hex.initial(4, 3, device=DEV)
+    h, _ = h.step(torch.full((4,), 4, device=DEV))
+    h, _ = h.step(torch.zeros(4, dtype=torch.long, device=DEV))
+    assert torch.equal(h.board, w2.board)
+
+    # random games to the end: the player only ever sees seat 0, every env finishes, rewards are -1/0/+1 and a reward
+    # arrives exactly with `terminal` (a loss is delivered through the opponent's winning reply)
+    torch.manual_seed(0)
+    w = hex.Random.initial(64, 4, device=DEV)
+    done = torch.zeros(64, dtype=torch.bool, device=DEV)
+    for _ in range(40):
+        a = torch.distributions.Categorical(probs=w.valid.float()).sample()
+        w, tr = w.step(a)
+        assert (w.seats == 0).all() and tr.rewards.shape == (64, 1)
+        assert ((tr.rewards[:, 0] != 0) == tr.terminal).all() and tr.rewards.abs().max() <= 1
+        assert (w.board[tr.terminal] == 0).all()
+        done |= tr.terminal
+    assert done.all()
+
+    # a one-seat search over it runs on the generic path (S = 1)
+    w = hex.Lazy.initial(8, 3, device=DEV)
+    m = mcts(w, validation.RandomAgent(), n_nodes=8)
+    assert not m.fused and m.stats.w.shape == (8, 8, 1) and (m.stats.n[:, 0] > 0).all()
+    assert torch.allclose(m.root().logits.float().exp().sum(-1), torch.ones(8, device=DEV), atol=2e-2)

@@ -4,6 +4,7 @@ import os
 import socket
 
 import numpy as np
+import pytest
 import torch
 import torch.multiprocessing as mp
 
@@ -128,3 +129,33 @@ def test_rollout_on_toy_world():
     trace = arena.rollout(worlds, [validation.RandomAgent(), validation.RandomAgent()], n_steps=4)
     assert trace.actions.shape == (4, 6) and trace.transitions.terminal.shape == (4, 6)
     assert trace.transitions.terminal[1::2].all() and not trace.transitions.terminal[0::2].any()
+    # per-agent decisions widened to every env: agent 0 moves on even steps, agent 1 on odd ones (analysis.py:28-45)
+    d0, d1 = trace.decisions['0'], trace.decisions['1']
+    assert d0.mask.shape == (4, 6) and d0.mask[0::2].all() and not d0.mask[1::2].any()
+    assert d1.mask[1::2].all() and not d1.mask[0::2].any()
+    assert (d0.actions[0::2] == trace.actions[0::2]).all() and (d0.actions[1::2] == -1).all()
+    assert torch.isnan(d1.logits[0::2]).all() and not torch.isnan(d1.logits[1::2]).any()
+    assert d0.v.shape == (4, 6, 2)
+
+
+def test_rollout_stop_conditions():
+    from boardlaw_amd import analysis, validation
+    agents = [validation.RandomAgent(), validation.RandomAgent()]
+    worlds = validation.WinnerLoser.initial(3, device='cpu')
+    assert analysis.rollout(worlds, agents, n_trajs=3).actions.shape[0] == 2        # 3 games end on the 2nd step
+    assert analysis.rollout(worlds, agents, n_reps=2).actions.shape[0] == 4         # every env has finished twice
+    with pytest.raises(AssertionError):
+        analysis.rollout(worlds, agents)
+    with pytest.raises(AssertionError):
+        analysis.rollout(worlds, agents, n_steps=1, n_trajs=1)
+
+
+def test_combine_decisions_missing_agent_steps():
+    """An agent that does not act at some step still gets a frame there: all blank, mask False."""
+    from boardlaw_amd import analysis, arrdict
+    m0 = torch.tensor([True, False, True])
+    d = arrdict.arrdict(actions=torch.tensor([4, 5]), logits=torch.zeros(2, 3))
+    out = analysis.combine_decisions([{0: d}, {}], [{0: m0}, {}])
+    assert out['0'].actions.tolist() == [[4, -1, 5], [-1, -1, -1]]
+    assert out['0'].mask.tolist() == [[True, False, True], [False, False, False]]
+    assert torch.isnan(out['0'].logits[1]).all()

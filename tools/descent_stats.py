@@ -19,7 +19,7 @@ for sim in range(1, 64):
         c = m.counters.cpu().numpy().astype(np.float64)
         lv, it = c[:, 0], c[:, 1]
         worst = int(np.argmax(c[:, 8] + c[:, 9]))
-        def row(x): return f'levels {x[0]:.1f} iters {x[1]:.1f} | cycles: loads {x[4]:.0f} terms {x[5]:.0f} folds {x[6]:.0f} update {x[7]:.0f} | descent {x[8]:.0f} expansion {x[9]:.0f}'
+        def row(x): return f'levels {x[0]:.1f} iters {x[1]:.1f} | cycles: loads {x[4]:.0f} (rows {x[10]:.0f}, +stats {x[11]:.0f}) terms {x[5]:.0f} folds {x[6]:.0f} update {x[7]:.0f} | descent {x[8]:.0f} expansion {x[9]:.0f}'
         print(f'sim {sim:2d}: levels max {lv.max():.0f} p99 {np.percentile(lv,99):.0f}; iters max {it.max():.0f}')
         print('   mean env :', row(c.mean(0)))
         print('   worst env:', row(c[worst]))
