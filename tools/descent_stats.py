@@ -8,7 +8,8 @@ from boardlaw_amd.mcts import MCTS
 from bench import premix
 
 gen = torch.Generator(device='cuda'); gen.manual_seed(0); torch.manual_seed(0)
-worlds = premix(Hex.initial(4096, 9), 27, gen)
+ENVS = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+worlds = premix(Hex.initial(ENVS, 9), 27, gen)
 net = networks.FCModel(worlds.obs_space, worlds.action_space, 512, 4).cuda()
 m = MCTS(worlds, n_nodes=64, count=True)
 m.initialize(net)
