@@ -1,8 +1,8 @@
 // bl_mlp.hip -- the leaf-evaluation network's body + head Linears (boardlaw/networks.py:10-40) as ONE gfx950 kernel.
 //
 // PyTorch runs this fp16-autocast MLP as 6 GEMM launches + elementwise launches (about 95 us per 4096-row batch on an
-// MI355X, launch- and epilogue-bound at this size).  Here a workgroup of 4 waves takes 32 rows through every layer:
-// activations live in LDS (residual stream X and relu(X)), weights stream from L2 straight into MFMA B fragments
+// MI355X, launch- and epilogue-bound at this size).  Here a workgroup of 4-8 waves takes 32 rows through every layer:
+// activations live in registers (residual stream x) and LDS (relu(x)), weights stream from L2 straight into MFMA fragments
 // (v_mfma_f32_32x32x16_f16), and the ReZero tail x + alpha*y / relu are the epilogue.  Rounding points are torch's
 // (Linear output, alpha*y, x + ., each rounded to f16); only the K-summation order inside a GEMM differs, so results
 // agree with the autocast module to f16 rounding (tests/test_gpu_parity.py::test_fused_mlp_matches_autocast).
@@ -127,29 +127,33 @@ __device__ __forceinline__ void rezero4(const float* acc4, uint2 bias, uint2 xol
     rout = make_uint2(__builtin_bit_cast(uint32_t, r01), __builtin_bit_cast(uint32_t, r23));
 }
 
-template <int NT, int WAVES>   // WAVES x NT x 32 == W: every wave owns NT 32-column tiles of a body layer's output
+// WAVES x PASSES x NT x 32 == W: every wave owns PASSES groups of NT 32-column tiles of a body layer's output and works
+// through them one group at a time (accumulators and weight ring sized for NT tiles; W = 1024 would not fit otherwise).
+template <int NT, int PASSES, int WAVES>
 __global__ void __launch_bounds__(WAVES * 64) mlp_kernel(Params p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int W = p.W, ld = W + 8;                  // +8 halves: rows 16 B apart in bank space, ds_read_b128 conflict-free
-    uint16_t* X = (uint16_t*)smem;                  // residual stream, f16 [32][ld]
-    // relu(X) / staged input, double-buffered at X + 32*ld*(1 + parity): a layer's epilogue writes the buffer the NEXT
-    // layer reads, so one barrier per layer suffices.  (Offsets from the one LDS base, not an array of pointers: the
-    // latter decays to generic pointers and turns every LDS access into a flat_load/flat_store.)
+    // Two activation buffers R(0), R(1) of [32][ld] f16: layer l reads R((l + par0) & 1) and writes the other one, so
+    // one barrier per layer suffices; the last layer writes the un-rectified neck (for the heads) instead of relu, and
+    // par0 is chosen so that the neck lands in R(0), leaving everything from R(1) on to the heads' staging.  (Offsets
+    // from the one LDS base, not an array of pointers: the latter decays to generic pointers and turns every LDS
+    // access into a flat_load/flat_store.)
+    uint16_t* R0 = (uint16_t*)smem;
+    const int par0 = (p.D + 1) & 1;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int row0 = blockIdx.x * 32;
-    const int n0 = wave * 32 * NT, tile0 = wave * NT;
     constexpr int NTHREADS = WAVES * 64;
     const int brow = lane & 31, hf = lane >> 5;     // this lane's batch row within the tile, and its feature half
 
     CLK(0)
     float16v acc[NT];
     Ring<NT> rg;
-    gemm_prefetch<NT>(rg, p.w0, p.K0pad, tile0, NT);          // weights first: their latency hides behind the staging
+    gemm_prefetch<NT>(rg, p.w0, p.K0pad, wave * PASSES * NT, NT);   // weights first: their latency hides behind the staging
     // stage the observation tile as 32-bit words (K0 is even: 2 planes per cell), zero-padding K0 -> K0pad and rows >= M
     {
         const int wpr = p.K0pad >> 1, wvalid = p.K0 >> 1;           // words per staged row / per real row
         const uint32_t* src = (const uint32_t*)p.obs;               // row r starts at word r * K0 / 2 (K0 even)
-        uint32_t* dst = (uint32_t*)(X + 32 * ld);
+        uint32_t* dst = (uint32_t*)(R0 + 32 * ld * par0);
         for (int r = tid >> 5; r < 32; r += NTHREADS / 32)
             for (int w = tid & 31; w < wpr; w += 32)
                 dst[r * (ld >> 1) + w] = (w < wvalid && row0 + r < p.M) ? src[(long)(row0 + r) * wvalid + w] : 0u;
@@ -157,48 +161,54 @@ __global__ void __launch_bounds__(WAVES * 64) mlp_kernel(Params p) {
     __syncthreads();
     CLK(1)
 
-    // intake Linear, then the ReZero blocks (networks.py:17-18): layer l reads relu buffer (l & 1), writes ((l + 1) & 1).
-    // A wave owns the same columns of the same rows in every layer, so its slice of the residual stream x stays in
-    // registers (packed f16) from layer to layer; only relu(x) -- the next GEMM's input -- goes through LDS.
-    uint2 xreg[NT][4];
+    // intake Linear, then the ReZero blocks (networks.py:17-18).  A wave owns the same columns of the same rows in every
+    // layer, so its slice of the residual stream x stays in registers (packed f16) from layer to layer; only relu(x)
+    // -- the next GEMM's input -- goes through LDS.
+    uint2 xreg[PASSES][NT][4];
 #pragma unroll
-    for (int t = 0; t < NT; t++) for (int g = 0; g < 4; g++) xreg[t][g] = make_uint2(0, 0);
+    for (int ps = 0; ps < PASSES; ps++) for (int t = 0; t < NT; t++) for (int g = 0; g < 4; g++) xreg[ps][t][g] = make_uint2(0, 0);
     for (int l = 0; l <= p.D; l++) {
         const uint16_t* Wl = l == 0 ? p.w0 : p.wb + (long)(l - 1) * W * W;
         const uint16_t* bl = l == 0 ? p.b0 : p.bb + (long)(l - 1) * W;
-        uint2 biasr[NT][4];                                       // issued now, needed after the GEMM
-#pragma unroll
-        for (int t = 0; t < NT; t++) for (int g = 0; g < 4; g++) biasr[t][g] = *(const uint2*)(bl + n0 + 32 * t + 8 * g + 4 * hf);
-        gemm_run<NT>(rg, X + 32 * ld * (1 + (l & 1)), ld, Wl, l == 0 ? p.K0pad : W, tile0, NT, acc);
-        CLK(2 + 3 * l)
-        if (l < p.D) gemm_prefetch<NT>(rg, p.wb + (long)l * W * W, W, tile0, NT);
+        const int Kl = l == 0 ? p.K0pad : W;
         half2v al2 = {(f16)0.f, (f16)0.f};
         if (l > 0) { const f16 a = (f16)p.alphas[l - 1]; al2[0] = a; al2[1] = a; }   // torch casts the f32 0-dim parameter to f16
-        uint16_t* Rn = X + 32 * ld * (1 + ((l + 1) & 1));
+        const uint16_t* Rin = R0 + 32 * ld * ((l + par0) & 1);
+        uint16_t* Rn = R0 + 32 * ld * ((l + 1 + par0) & 1);
 #pragma unroll
-        for (int t = 0; t < NT; t++) {
+        for (int ps = 0; ps < PASSES; ps++) {
+            const int tile0 = (wave * PASSES + ps) * NT, n0 = tile0 * 32;
+            uint2 biasr[NT][4];                                       // issued now, needed after the GEMM
 #pragma unroll
-            for (int g = 0; g < 4; g++) {
-                const int f0 = n0 + 32 * t + 8 * g + 4 * hf;             // 4 consecutive features of batch row `brow`
-                const uint2 bias = biasr[t][g];
-                const uint2 xold = xreg[t][g];
-                const float a4[4] = {acc[t][4 * g], acc[t][4 * g + 1], acc[t][4 * g + 2], acc[t][4 * g + 3]};
-                uint2 xo, ro;
-                rezero4(a4, bias, xold, al2, l == 0, xo, ro);
-                xreg[t][g] = xo;
-                if (l == p.D) *(uint2*)(X + brow * ld + f0) = xo;     // only the heads read the neck from LDS
-                *(uint2*)(Rn + brow * ld + f0) = ro;
+            for (int t = 0; t < NT; t++) for (int g = 0; g < 4; g++) biasr[t][g] = *(const uint2*)(bl + n0 + 32 * t + 8 * g + 4 * hf);
+            gemm_run<NT>(rg, Rin, ld, Wl, Kl, tile0, NT, acc);
+            CLK(2 + 3 * l)
+            // next weights in flight before the epilogue: this layer's next pass, or the next layer's first pass
+            if (ps + 1 < PASSES) gemm_prefetch<NT>(rg, Wl, Kl, tile0 + NT, NT);
+            else if (l < p.D) gemm_prefetch<NT>(rg, p.wb + (long)l * W * W, W, wave * PASSES * NT, NT);
+#pragma unroll
+            for (int t = 0; t < NT; t++) {
+#pragma unroll
+                for (int g = 0; g < 4; g++) {
+                    const int f0 = n0 + 32 * t + 8 * g + 4 * hf;             // 4 consecutive features of batch row `brow`
+                    const float a4[4] = {acc[t][4 * g], acc[t][4 * g + 1], acc[t][4 * g + 2], acc[t][4 * g + 3]};
+                    uint2 xo, ro;
+                    rezero4(a4, biasr[t][g], xreg[ps][t][g], al2, l == 0, xo, ro);
+                    xreg[ps][t][g] = xo;
+                    *(uint2*)(Rn + brow * ld + f0) = (l == p.D) ? xo : ro;    // the heads read the neck itself
+                }
             }
         }
         CLK(3 + 3 * l)
         __syncthreads();
         CLK(4 + 3 * l)
     }
+    const uint16_t* X = R0;                                        // the neck (par0 makes the last layer write R(0))
     // heads' Linears on the un-rectified neck.  The NHpad/32 output tiles are few (3 for 9x9), so each tile's K range is
-    // split over two waves (waves 2t and 2t+1); the upper half's partial sums go through LDS (the relu buffers are free
-    // now) to the lower half's wave, which adds them in a fixed order and stores.
+    // split over two waves (waves 2t and 2t+1); the upper half's partial sums go through LDS (R(1) is free now) to the
+    // lower half's wave, which adds them in a fixed order and stores.
     const int htiles = p.NHpad / 32, KBh = W >> 6;
-    float* Part = (float*)(X + 32 * ld);                          // [unit][16][64] f32, 4 KiB per unit
+    float* Part = (float*)(R0 + 32 * ld);                         // [unit][16][64] f32, 4 KiB per unit
     for (int round = 0; round * WAVES < 2 * htiles; round++) {    // same trip count for every wave: uniform barriers
         const int u = round * WAVES + wave;
         const bool active = u < 2 * htiles;
@@ -231,7 +241,7 @@ __global__ void __launch_bounds__(WAVES * 64) mlp_kernel(Params p) {
                 }
             }
         }
-        __syncthreads();                                          // every wave has finished reading the relu buffers' owner X
+        __syncthreads();
         if (active && khalf == 1) {
 #pragma unroll
             for (int i = 0; i < 16; i++) Part[(t0 * 16 + i) * 64 + lane] = hacc[i];
@@ -277,29 +287,30 @@ extern "C" int bl_mlp_forward_f16(const void* obs, int M, int K0, const void* w0
     if (W % 128 != 0 || W < 128 || W > 1024 || K0pad % 64 != 0 || K0pad < K0 || K0pad > W || NHpad % 32 != 0 || NHpad < NH) return BL_ETOOBIG;
     Params p{(const uint16_t*)obs, (const uint16_t*)w0, (const uint16_t*)b0, (const uint16_t*)wb, (const uint16_t*)bb, alphas,
              (const uint16_t*)wh, (const uint16_t*)bh, (uint16_t*)policy_out, (uint16_t*)value_out, M, K0, K0pad, W, D, NH, NHpad};
-    // X + two R buffers; the heads reuse the R region for split-K partials and the output staging
-    size_t lds = (size_t)3 * 32 * (W + 8) * 2;
-    const size_t lds_heads = (size_t)32 * (W + 8) * 2 + (size_t)(NHpad / 32) * 16 * 64 * 4 + (size_t)32 * NHpad * 2;
-    if (lds_heads > lds) lds = lds_heads;
+    // two activation buffers; the heads keep the neck in the first and stage split-K partials + outputs after it
+    const size_t buf = (size_t)32 * (W + 8) * 2;
+    const size_t staging = (size_t)(NHpad / 32) * 16 * 64 * 4 + (size_t)32 * NHpad * 2;
+    const size_t lds = buf + (staging > buf ? staging : buf);
     if (lds > 160 * 1024) return BL_ETOOBIG;
     const dim3 grid((M + 31) / 32);
     hipStream_t hs = (hipStream_t)stream;
-    // above the 64 KiB default from W = 256 up (gfx950 has 160 KiB per CU)
-#define BL_MLP_LAUNCH(NT, WAVES)                                                                                       \
+    // above the 64 KiB default the limit has to be raised per kernel (gfx950 has 160 KiB per CU)
+#define BL_MLP_LAUNCH(NT, PASSES, WAVES)                                                                               \
     {                                                                                                                  \
-        static bool raised = false;                                                                                    \
-        if (lds > 65536 && !raised) {                                                                                  \
-            if (hipFuncSetAttribute((const void*)mlp_kernel<NT, WAVES>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return BL_ELAUNCH; \
-            raised = true;                                                                                             \
+        static size_t raised = 65536;                                                                                  \
+        if (lds > raised) {                                                                                            \
+            if (hipFuncSetAttribute((const void*)mlp_kernel<NT, PASSES, WAVES>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return BL_ELAUNCH; \
+            raised = lds;                                                                                              \
         }                                                                                                              \
-        hipLaunchKernelGGL((mlp_kernel<NT, WAVES>), grid, dim3(WAVES * 64), lds, hs, p);                               \
+        hipLaunchKernelGGL((mlp_kernel<NT, PASSES, WAVES>), grid, dim3(WAVES * 64), lds, hs, p);                       \
     }
     // 8 waves (two per SIMD) from W = 256 up: while one wave waits for its weight fragments the other issues MFMAs
     switch (W / 128) {
-        case 1: BL_MLP_LAUNCH(1, 4) break;
-        case 2: BL_MLP_LAUNCH(1, 8) break;
-        case 4: BL_MLP_LAUNCH(2, 8) break;
-        case 8: BL_MLP_LAUNCH(4, 8) break;
+        case 1: BL_MLP_LAUNCH(1, 1, 4) break;
+        case 2: BL_MLP_LAUNCH(1, 1, 8) break;
+        case 4: BL_MLP_LAUNCH(2, 1, 8) break;
+        case 6: BL_MLP_LAUNCH(1, 3, 8) break;
+        case 8: BL_MLP_LAUNCH(2, 2, 8) break;
         default: return BL_ETOOBIG;
     }
 #undef BL_MLP_LAUNCH

@@ -97,8 +97,11 @@ class Inference:
         m = self.model
         blocks = list(m.body)
         W, K0 = blocks[0].weight.shape
-        return (W % 128 == 0 and 128 <= W <= 512 and -(-K0 // 64) * 64 <= W and type(m.policy).__name__ in ('MaskedOutput', 'DiscreteOutput')
-                and blocks[0].weight.is_cuda)
+        A = m.policy.core.weight.shape[0]
+        NHpad = -(-(A + 1) // 32) * 32
+        buf, staging = 32 * (W + 8) * 2, (NHpad // 32) * 4096 + 32 * NHpad * 2     # bl_mlp_forward_f16's LDS budget
+        return (W in (128, 256, 512, 768, 1024) and -(-K0 // 64) * 64 <= W and buf + max(buf, staging) <= 160 * 1024
+                and type(m.policy).__name__ in ('MaskedOutput', 'DiscreteOutput') and blocks[0].weight.is_cuda)
 
     def _stamp(self):
         srcs, alphas = self._sources()

@@ -144,7 +144,8 @@ int bl_rezero_relu_f16(const void* x, const void* y, const float* alpha, void* x
  * Matrices are f16 (out, in): w0 (W,K0pad) zero-padded from (W,K0); wb (D,W,W); wh (NHpad,W) with rows 0..NH-2 the
  * policy Linear, row NH-1 the value Linear, zero rows after -- each PACKED fragment-major so that a wave's MFMA operand
  * loads are contiguous:  packed[n/32][k/64][s][lane][j] = M[32*(n/32) + (lane&31)][64*(k/64) + 32*(lane>>5) + 8*s + j],
- * s < 4, lane < 64, j < 8 (boardlaw_amd/networks.py: pack_fragment_major).  W % 128 == 0, K0pad % 64 == 0, NHpad % 32 == 0.
+ * s < 4, lane < 64, j < 8 (boardlaw_amd/networks.py: pack_fragment_major).  W in {128, 256, 512, 768, 1024}, K0pad % 64 == 0,
+ * K0pad <= W, NHpad % 32 == 0; BL_ETOOBIG otherwise, or when the two activation buffers + head staging exceed 160 KiB of LDS.
  * Writes policy_out (M,NH-1) f16 and value_out (M) f16.  Same rounding points as torch; GEMM summation order differs. */
 int bl_mlp_forward_f16(const void* obs /*f16 (M,K0)*/, int M, int K0, const void* w0, const void* b0, const void* wb,
                        const void* bb, const float* alphas /*(D) f32*/, const void* wh, const void* bh, int W, int D,

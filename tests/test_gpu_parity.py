@@ -487,7 +487,7 @@ def test_sharded_search_with_merged_qrange_equals_unsharded(oracle):
         assert same == merge
 
 
-@pytest.mark.parametrize('S,width,depth,B', [(9, 512, 4, 4096), (7, 128, 4, 1000), (8, 256, 4, 33), (6, 128, 1, 64), (13, 512, 2, 300), (3, 128, 4, 5000)])
+@pytest.mark.parametrize('S,width,depth,B', [(9, 512, 4, 4096), (7, 128, 4, 1000), (8, 256, 4, 33), (6, 128, 1, 64), (13, 512, 2, 300), (3, 128, 4, 5000), (13, 1024, 8, 1024), (11, 768, 3, 200), (19, 1024, 2, 70), (9, 512, 5, 100)])
 def test_fused_mlp_matches_autocast(S, width, depth, B):
     """bl_mlp_forward_f16 (one MFMA kernel for all Linears) vs the module under fp16 autocast: same rounding points,
     different GEMM summation order => a tolerance test.  Tolerance: 3 f16 ulps of the largest activation scale plus

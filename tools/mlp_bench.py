@@ -13,16 +13,17 @@ def timeit(f, reps=50):
     b.record(); torch.cuda.synchronize()
     return 1e3 * a.elapsed_time(b) / reps
 
-S, width, depth = 9, 512, 4
+S, width, depth = (int(x) for x in (sys.argv[1:4] if len(sys.argv) >= 4 else (9, 512, 4)))
+A = S * S
 net = networks.FCModel(heads.Tensor((S, S, 2)), heads.Masked(S * S), width=width, depth=depth).cuda()
 fused, plan = networks.Inference(net, fused=True), networks.Inference(net)
 fused.refresh(); plan.refresh()
 class W: pass
-for B in (32, 256, 1024, 2048, 4096, 8192, 16384, 32768):
+for B in (32, 256, 1024, 2048, 4096, 8192, 16384):
     w = W(); w.obs = (torch.rand(B, S, S, 2, device='cuda') < .3).half()
     with torch.no_grad(), torch.autocast('cuda'):
         tf = timeit(lambda: fused.raw(w)); tp = timeit(lambda: plan.raw(w)); tm = timeit(lambda: net.raw(w))
-    flops = 2 * B * (162 * 512 + 4 * 512 * 512 + 512 * 82)
+    flops = 2 * B * (2 * A * width + depth * width * width + width * (A + 1))
     print(f'B {B:6d}: fused {tf:7.1f} us ({flops / tf / 1e6:6.1f} TFLOP/s)   torch-gemm plan {tp:7.1f} us   autocast module {tm:7.1f} us')
 
 
