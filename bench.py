@@ -102,16 +102,23 @@ def cpu_baseline(seconds_budget=25.0):
 
 
 def main():
+    global BOARD, NODES, WIDTH, DEPTH
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--envs', type=int, default=ENVS, help='envs per GPU (the metric is quoted at 4096)')
+    ap.add_argument('--boardsize', type=int, default=BOARD, help='exploration only: the metric is quoted on 9x9')
+    ap.add_argument('--nodes', type=int, default=NODES, help='exploration only: sims per move (metric: 64)')
+    ap.add_argument('--width', type=int, default=WIDTH, help='exploration only: FCModel width (metric: 512)')
+    ap.add_argument('--depth', type=int, default=DEPTH, help='exploration only: FCModel depth (metric: 4)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--plain-network', action='store_true', help='run the nn.Module under autocast instead of the fp16 inference plan')
     ap.add_argument('--torch-gemms', action='store_true', help='keep the Linears as torch (hipBLASLt) GEMMs instead of the fused MFMA kernel')
     ap.add_argument('--eager', action='store_true', help='launch kernel by kernel instead of replaying a HIP graph per move')
     args = ap.parse_args()
+    BOARD, NODES, WIDTH, DEPTH = args.boardsize, args.nodes, args.width, args.depth
+    default_shape = (BOARD, NODES, WIDTH, DEPTH) == (9, 64, 512, 4)
 
     assert torch.cuda.is_available(), 'bench.py needs an MI355X; there is no CPU path'
     from boardlaw_amd import parallel
@@ -184,15 +191,16 @@ def main():
         achieved = per_launch / (kernel_us * 1e-6) / 1e9
         traffic = None
         tpath = os.path.join(ROOT, 'profiles', 'r01_traffic.json')
-        if args.envs == ENVS and os.path.exists(tpath):
+        if args.envs == ENVS and default_shape and os.path.exists(tpath):
             # HBM-side bytes per launch from rocprofv3 PMC passes (FETCH_SIZE + WRITE_SIZE), see profiles/README.md
             traffic = json.load(open(tpath))['traffic_bytes_per_launch']
         out = {
             'metric': 'mcts_sims_per_sec', 'value': value, 'unit': 'sims/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps, 'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': f'9x9 Hex, {args.envs} envs/GPU x {NODES} sims/move, FCModel {WIDTH}x{DEPTH} fp16 autocast '
-                                   '(BASELINE config 2); step = one self-play move of the batch',
+            'config': {'workload': f'{BOARD}x{BOARD} Hex, {args.envs} envs/GPU x {NODES} sims/move, FCModel {WIDTH}x{DEPTH} fp16 autocast'
+                                   + (' (BASELINE config 2)' if default_shape and args.envs == ENVS else ' (NOT the metric\'s configuration)')
+                                   + '; step = one self-play move of the batch',
                        'envs_per_gpu': args.envs, 'nodes': NODES, 'boardsize': BOARD, 'parallelism': f'replicas x{world}', 'launch': launch,
                        'd_policy_evals_per_descent': round(d, 3), 'k_child_lookups_per_descent': round(k, 3),
                        'newton_iters_per_eval': round(its, 3),
@@ -203,7 +211,7 @@ def main():
                          'kernel_us': kernel_us, 'bytes_per_launch': per_launch, 'launches_timed': len(timer.pairs),
                          'timing': 'HIP events around every launch ' + ('inside the timed region' if args.eager else 'in an eager re-run of the same moves right after the timed (graph-replay) region')},
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and default_shape:
             out['cpu_baseline'] = cpu_baseline()
         print(json.dumps(out))
     if world > 1:
