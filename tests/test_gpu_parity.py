@@ -208,8 +208,10 @@ def test_whole_search_replay(name, fused):
         assert np.array_equal(to_np(trans.rewards), g[p + 'step_rewards']) and np.array_equal(to_np(trans.terminal), g[p + 'step_terminal'])
 
 
-def oracle_search(oracle, board, seats, T, rands, stats=None):
+def oracle_search(oracle, board, seats, T, rands, stats=None, c_puct=None):
     s = OracleSearch(oracle, board, seats, T)
+    if c_puct is not None:
+        s.c_puct = np.ascontiguousarray(c_puct.astype(np.float16).view(np.uint16))
     obs = oracle.hex_observe(board, seats)
     valid = (obs == 0).all(-1).reshape(board.shape[0], -1)
     l, v = hash_network_np(board, seats, valid)
@@ -262,6 +264,32 @@ def test_full_size_search_vs_oracle(oracle, S, B, T):
     n = to_np(m.stats.n)
     assert (n[:, 0] == 2 * (T - 1)).all()
     assert (to_np(m.tree.parents)[:, 1:] < np.arange(1, T)[None]).all()
+
+
+@pytest.mark.parametrize('S,B,T', [(9, 512, 64), (5, 200, 24)])
+def test_search_with_per_env_c_puct(oracle, S, B, T):
+    """c_puct is a per-env f16 array in the reference's struct (mcts/cpp/common.h:25-33): from 1/256 (value-driven: long
+    Newton runs, deep narrow trees) to 8 (prior-driven).  Whole search against the oracle, everything identical."""
+    from boardlaw_amd.hex import Hex
+    from boardlaw_amd.mcts import MCTS
+    board, seats = premixed(oracle, B, S, (S * S) // 3, seed=77 + S)
+    rng = np.random.default_rng(5)
+    rands = rng.random((T - 1, B, T)).astype(np.float16).view(np.uint16)
+    c = (2.0 ** rng.integers(-8, 4, B)).astype(np.float32) * (1 + rng.random(B).astype(np.float32) / 2)
+    want = oracle_search(oracle, board, seats, T, rands, c_puct=c)
+
+    world = Hex(board=torch.from_numpy(board).to(DEV), seats=torch.from_numpy(seats).to(DEV))
+    net = HashNetwork(DEV)
+    m = MCTS(world, n_nodes=T, rng=ReplayRng(rands, DEV), noise_eps=0.)
+    m.c_puct.copy_(torch.from_numpy(c).to(DEV).half())
+    d = net(world)
+    m.plant_root(d.logits, d.v)
+    for _ in range(T - 1):
+        m.simulate(net)
+    for mine, theirs in [(m.tree.children, want.children), (m.tree.parents, want.parents), (m.stats.n, want.n),
+                         (m.stats.w, want.w), (m.worlds.board, want.boards), (m.decisions.logits, want.logits)]:
+        assert np.array_equal(to_np(mine), theirs)
+    assert np.array_equal(bits16(m.root_probs()), want.root_probs())
 
 
 def test_toy_worlds_reference_goldens():
