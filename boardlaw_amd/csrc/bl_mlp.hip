@@ -41,6 +41,34 @@ struct Params {
     int M, K0, K0pad, W, D, NH, NHpad;
 };
 
+// What bl_sim_finish does for a leaf (heads, store, backup, next q range), as this kernel's epilogue: bl_sim_infer_finish.
+// Field meanings as in bl_search_t; qrange points at the row the NEXT descent reads.
+struct FinArgs {
+    uint16_t* logits; uint16_t* v; uint16_t* w; int16_t* n; const uint16_t* rewards; const uint8_t* terminal;
+    const int16_t* path; uint32_t* qrange; const int16_t* leaves; const int32_t* leaf_seats; const uint8_t* valid;
+    int T, A, Wsm, iters;
+};
+#define BLM_QSLOTS 64
+#define BLM_QSTRIDE 64
+__device__ __forceinline__ uint32_t enc(float f) {      // order-preserving float -> u32 (as in bl_kernels.hip)
+    const uint32_t b = __builtin_bit_cast(uint32_t, f);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+template <int CTRL, int RM>
+__device__ __forceinline__ int dpp_i(int old, int v) { return __builtin_amdgcn_update_dpp(old, v, CTRL, RM, 0xf, false); }
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {      // row_shr 1,2,4,8, row_bcast 15/31: lane 63 ends with the max
+    v = max(v, (uint32_t)dpp_i<0x111, 0xf>(0, (int)v)); v = max(v, (uint32_t)dpp_i<0x112, 0xf>(0, (int)v));
+    v = max(v, (uint32_t)dpp_i<0x114, 0xf>(0, (int)v)); v = max(v, (uint32_t)dpp_i<0x118, 0xf>(0, (int)v));
+    v = max(v, (uint32_t)dpp_i<0x142, 0xa>(0, (int)v)); v = max(v, (uint32_t)dpp_i<0x143, 0xc>(0, (int)v));
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+__device__ __forceinline__ float dpp_next_lane(float beyond, float x) {   // lane j <- x[j + 1]; lane 63 <- `beyond`
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, beyond), __builtin_bit_cast(int, x), 0x130, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float readlane_f(float v, int lane) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
+}
+
 // One layer, transposed: acc[t] = W[32 features of tile t][K] . in[32 rows][K]^T, i.e. D[feature][batch row].  With the
 // weights as the A operand, a lane's accumulator registers are 4 groups of 4 CONSECUTIVE features of ONE batch row
 // (feature = 32*tile + (i & 3) + 8*(i >> 2) + 4*(lane >> 5), row = lane & 31), so the epilogue moves 8 bytes at a time.
@@ -129,8 +157,8 @@ __device__ __forceinline__ void rezero4(const float* acc4, uint2 bias, uint2 xol
 
 // WAVES x PASSES x NT x 32 == W: every wave owns PASSES groups of NT 32-column tiles of a body layer's output and works
 // through them one group at a time (accumulators and weight ring sized for NT tiles; W = 1024 would not fit otherwise).
-template <int NT, int PASSES, int WAVES>
-__global__ void __launch_bounds__(WAVES * 64) mlp_kernel(Params p) {
+template <int NT, int PASSES, int WAVES, bool FINISH>
+__global__ void __launch_bounds__(WAVES * 64) mlp_kernel(Params p, FinArgs f) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int W = p.W, ld = W + 8;                  // +8 halves: rows 16 B apart in bank space, ds_read_b128 conflict-free
     // Two activation buffers R(0), R(1) of [32][ld] f16: layer l reads R((l + par0) & 1) and writes the other one, so
@@ -146,6 +174,15 @@ __global__ void __launch_bounds__(WAVES * 64) mlp_kernel(Params p) {
     const int brow = lane & 31, hf = lane >> 5;     // this lane's batch row within the tile, and its feature half
 
     CLK(0)
+    // FINISH: this wave finishes the tile's envs 4*wave .. 4*wave+3 after the heads (WAVES == 8).  Everything that step
+    // reads from the tree is requested after the staging barrier (paths, valid masks) and after the second layer (the
+    // nodes those paths name), so that the round trips run under the GEMMs without holding up the staging (vmcnt
+    // retires in order): lane j holds the j-th node of the env's recorded descent (bl_sim_expand's path) and,
+    // separately, node slot `lane` of the env (T <= 64) for the q range.
+    constexpr int EPW = 4;
+    int fb[EPW], fleaf[EPW], fmover[EPW], flen[EPW], fnode[EPW], fvalid[EPW][2];
+    int fterm[EPW], fn[EPW], fallN[EPW];
+    uint32_t frew[EPW], fw[EPW], fallW[EPW];
     float16v acc[NT];
     Ring<NT> rg;
     gemm_prefetch<NT>(rg, p.w0, p.K0pad, wave * PASSES * NT, NT);   // weights first: their latency hides behind the staging
@@ -159,6 +196,20 @@ __global__ void __launch_bounds__(WAVES * 64) mlp_kernel(Params p) {
                 dst[r * (ld >> 1) + w] = (w < wvalid && row0 + r < p.M) ? src[(long)(row0 + r) * wvalid + w] : 0u;
     }
     __syncthreads();
+    if constexpr (FINISH) {
+#pragma unroll
+        for (int e = 0; e < EPW; e++) {
+            const int b = row0 + EPW * wave + e;
+            fb[e] = b < p.M ? b : -1;
+            const long bb = b < p.M ? b : 0;
+            fleaf[e] = f.leaves[bb]; fmover[e] = f.leaf_seats[bb];
+            const int16_t* path = f.path + bb * (f.T + 2);
+            flen[e] = path[0];
+            fnode[e] = lane < f.T ? (int)path[1 + lane] : 0;
+            fvalid[e][0] = lane < f.A ? (int)f.valid[bb * f.A + lane] : 0;
+            fvalid[e][1] = lane + 64 < f.A ? (int)f.valid[bb * f.A + lane + 64] : 0;
+        }
+    }
     CLK(1)
 
     // intake Linear, then the ReZero blocks (networks.py:17-18).  A wave owns the same columns of the same rows in every
@@ -202,6 +253,20 @@ __global__ void __launch_bounds__(WAVES * 64) mlp_kernel(Params p) {
         CLK(3 + 3 * l)
         __syncthreads();
         CLK(4 + 3 * l)
+        if (FINISH && l == (p.D >= 1 ? 1 : 0)) {
+            // the paths requested after the staging have landed by now; what they point at has the remaining layers to arrive
+#pragma unroll
+            for (int e = 0; e < EPW; e++) {
+                const long envbase = (long)(fb[e] < 0 ? 0 : fb[e]) * f.T;
+                flen[e] = __builtin_amdgcn_readfirstlane(flen[e]);
+                const bool in = lane < flen[e];
+                const long i = envbase + (in ? fnode[e] : 0);
+                fterm[e] = f.terminal[i]; fn[e] = f.n[i];
+                frew[e] = *(const uint32_t*)(f.rewards + i * 2); fw[e] = *(const uint32_t*)(f.w + i * 2);
+                const long t = envbase + (lane < f.T ? lane : 0);
+                fallW[e] = *(const uint32_t*)(f.w + t * 2); fallN[e] = f.n[t];
+            }
+        }
     }
     const uint16_t* X = R0;                                        // the neck (par0 makes the last layer write R(0))
     // heads' Linears on the un-rectified neck.  The NHpad/32 output tiles are few (3 for 9x9), so each tile's K range is
@@ -260,15 +325,126 @@ __global__ void __launch_bounds__(WAVES * 64) mlp_kernel(Params p) {
         }
         __syncthreads();
     }
-    // coalesced stores: a wave writes one row's NH-1 policy outputs as consecutive halves
-    {
-        const uint16_t* Out = (const uint16_t*)(Part + htiles * 16 * 64);
+    const uint16_t* Out = (const uint16_t*)(Part + htiles * 16 * 64);
+    if constexpr (!FINISH) {
+        // coalesced stores: a wave writes one row's NH-1 policy outputs as consecutive halves
         for (int r = wave; r < 32; r += WAVES) {
             if (row0 + r < p.M) {
-                for (int f = lane; f < p.NH - 1; f += 64) p.policy[(long)(row0 + r) * (p.NH - 1) + f] = Out[r * p.NHpad + f];
+                for (int fi = lane; fi < p.NH - 1; fi += 64) p.policy[(long)(row0 + r) * (p.NH - 1) + fi] = Out[r * p.NHpad + fi];
             }
         }
         if (tid < 32 && row0 + tid < p.M) p.value[row0 + tid] = Out[tid * p.NHpad + p.NH - 1];
+    } else {
+        // ---- bl_sim_finish's work for this wave's four envs, operation for operation as in bl_kernels.hip:
+        // sim_finish_kernel (heads with torch's order; backup cuda.cu:205-236; transition_q's range), but PHASE by phase
+        // across the four envs so that their cross-lane exchanges and LDS trips overlap instead of queueing.
+        uint32_t* scr = (uint32_t*)(Out + 32 * p.NHpad) + wave * (EPW * 128);   // per wave and env: 64 w-pairs + 64 n
+        const int A = f.A, T = f.T, Wsm = f.Wsm, iters = f.iters;
+        const bool two = iters > 1;
+        long envbase[EPW]; int leaf[EPW];
+        float ev[EPW][2], mx[EPW], sum[EPW];
+        // policy head: lane l < Wsm holds actions l + it * Wsm; A <= 128 here, so that is register `it` of the valid bytes
+#pragma unroll
+        for (int e = 0; e < EPW; e++) {
+            const int r = EPW * wave + e;
+            envbase[e] = (long)(fb[e] < 0 ? 0 : fb[e]) * T;
+            leaf[e] = __builtin_amdgcn_readfirstlane(fleaf[e]);
+            ev[e][0] = -INFINITY; ev[e][1] = -INFINITY;
+            if (lane < Wsm) {
+                if (lane < A) ev[e][0] = fvalid[e][0] ? h2f(Out[r * p.NHpad + lane]) : -INFINITY;
+                if (two && lane + Wsm < A) ev[e][1] = fvalid[e][1] ? h2f(Out[r * p.NHpad + lane + Wsm]) : -INFINITY;
+            }
+            mx[e] = two ? ((ev[e][0] > ev[e][1]) ? ev[e][0] : ev[e][1]) : ev[e][0];
+        }
+        for (int off = Wsm / 2; off > 0; off /= 2) {
+#pragma unroll
+            for (int e = 0; e < EPW; e++) { const float o = __shfl_xor(mx[e], off, 64); mx[e] = (mx[e] < o) ? o : mx[e]; }
+        }
+#pragma unroll
+        for (int e = 0; e < EPW; e++) { sum[e] = 0.f; sum[e] += expf(ev[e][0] - mx[e]); if (two) sum[e] += expf(ev[e][1] - mx[e]); }
+        for (int off = Wsm / 2; off > 0; off /= 2) {
+#pragma unroll
+            for (int e = 0; e < EPW; e++) sum[e] = sum[e] + __shfl_xor(sum[e], off, 64);
+        }
+        uint16_t vb0[EPW], vb1[EPW];
+#pragma unroll
+        for (int e = 0; e < EPW; e++) {
+            const int r = EPW * wave + e;
+            const float lsum = logf(sum[e]);
+            if (fb[e] >= 0 && lane < Wsm) {
+                uint16_t* dst = f.logits + (envbase[e] + leaf[e]) * A;
+                if (lane < A) dst[lane] = f2h(ev[e][0] - mx[e] - lsum);
+                if (two && lane + Wsm < A) dst[lane + Wsm] = f2h(ev[e][1] - mx[e] - lsum);
+            }
+            // value head
+            const uint16_t tv = f2h(tanhf(h2f(Out[r * p.NHpad + p.NH - 1])));
+            const int mover = __builtin_amdgcn_readfirstlane(fmover[e]);
+            vb0[e] = (mover == 0) ? tv : (uint16_t)(tv ^ 0x8000u); vb1[e] = (uint16_t)(vb0[e] ^ 0x8000u);
+            if (fb[e] >= 0 && lane == 0) { f.v[(envbase[e] + leaf[e]) * 2] = vb0[e]; f.v[(envbase[e] + leaf[e]) * 2 + 1] = vb1[e]; }
+        }
+        // backup (cuda.cu:205-236), leaf -> root: node j's value is v_j = (terminal_j ? 0 : v_{j+1}) + r_j with v_len the
+        // leaf evaluation.  Every lane applies that step to its right neighbour's current value at once; after k rounds
+        // the last k nodes of the path are final (each re-evaluation reads a final neighbour and recomputes the same
+        // sum), so maxlen rounds finish all four envs' paths -- two DPP instructions per round and env instead of a
+        // scalar walk.  w_j = rn16(w_j + rn16(v_j)) then needs no order at all.
+        float x0[EPW], x1[EPW], r0[EPW], r1[EPW];
+        int maxlen = 0;
+#pragma unroll
+        for (int e = 0; e < EPW; e++) {
+            x0[e] = h2f(vb0[e]); x1[e] = h2f(vb1[e]);                          // lanes >= len keep the leaf evaluation
+            r0[e] = h2f((uint16_t)frew[e]); r1[e] = h2f((uint16_t)(frew[e] >> 16));
+            if (fb[e] < 0) flen[e] = 0;
+            maxlen = flen[e] > maxlen ? flen[e] : maxlen;
+        }
+        for (int k = 0; k < maxlen; k++) {
+#pragma unroll
+            for (int e = 0; e < EPW; e++) {
+                const float n0 = dpp_next_lane(h2f(vb0[e]), x0[e]), n1 = dpp_next_lane(h2f(vb1[e]), x1[e]);
+                if (lane < flen[e]) { x0[e] = (fterm[e] ? 0.f : n0) + r0[e]; x1[e] = (fterm[e] ? 0.f : n1) + r1[e]; }
+            }
+        }
+        float w0[EPW], w1[EPW];
+#pragma unroll
+        for (int e = 0; e < EPW; e++) {
+            w0[e] = h2f(f2h(h2f((uint16_t)fw[e]) + h2f(f2h(x0[e]))));
+            w1[e] = h2f(f2h(h2f((uint16_t)(fw[e] >> 16)) + h2f(f2h(x1[e]))));
+        }
+        // stores, and the q range over all T slots of each env with the path's nodes replaced by their new statistics:
+        // through this wave's LDS scratch (LDS operations of one wave execute in order)
+        volatile uint32_t* vs = scr;
+        uint32_t wnew[EPW]; int nnew[EPW];
+#pragma unroll
+        for (int e = 0; e < EPW; e++) {
+            wnew[e] = (uint32_t)f2h(w0[e]) | ((uint32_t)f2h(w1[e]) << 16);
+            nnew[e] = (int)(int16_t)(fn[e] + 2);                            // n += 1 once per seat (cuda.cu:230), int16 wrap kept
+            if (lane < flen[e]) {
+                const long i = envbase[e] + fnode[e];
+                *(uint32_t*)(f.w + i * 2) = wnew[e];
+                f.n[i] = (int16_t)nnew[e];
+            }
+            if (lane < T) { vs[e * 128 + lane] = fallW[e]; vs[e * 128 + 64 + lane] = (uint32_t)fallN[e]; }
+        }
+#pragma unroll
+        for (int e = 0; e < EPW; e++) if (lane < flen[e]) { vs[e * 128 + fnode[e]] = wnew[e]; vs[e * 128 + 64 + fnode[e]] = (uint32_t)nnew[e]; }
+        uint32_t nmin = 0, vmax = 0;
+#pragma unroll
+        for (int e = 0; e < EPW; e++) {
+            if (fb[e] >= 0 && lane < T) {
+                const uint32_t ww = vs[e * 128 + lane];
+                const float den = (float)(int)(int16_t)vs[e * 128 + 64 + lane] + 1.e-4f;
+                const uint32_t e0 = enc(h2f((uint16_t)ww) / den), e1 = enc(h2f((uint16_t)(ww >> 16)) / den);
+                nmin = max(nmin, max(~e0, ~e1)); vmax = max(vmax, max(e0, e1));
+            }
+        }
+        // max is associative: one reduction and one conditional atomic pair for the wave's four envs
+        nmin = wave_max_u32(nmin); vmax = wave_max_u32(vmax);
+        if (lane == 0 && fb[0] >= 0) {
+            uint32_t* q = f.qrange + BLM_QSTRIDE * ((blockIdx.x * WAVES + wave) % BLM_QSLOTS);
+            // unconditional: with one pair per wave (1024 per launch over 64 slots) the atomics are cheap, and a checking
+            // load first would put a round trip at the very end of every workgroup
+            atomicMax(q, nmin);
+            atomicMax(q + 1, vmax);
+        }
     }
     CLK(40)
 }
@@ -278,35 +454,32 @@ __global__ void __launch_bounds__(WAVES * 64) mlp_kernel(Params p) {
 #ifdef BL_MLP_CLK
 extern "C" int bl_mlp_debug_clk(long long* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(blmlp::g_debug_clk), 64 * 8) == hipSuccess ? 0 : -3; }
 #endif
-extern "C" int bl_mlp_forward_f16(const void* obs, int M, int K0, const void* w0, const void* b0, const void* wb,
-                                  const void* bb, const float* alphas, const void* wh, const void* bh, int W, int D,
-                                  int K0pad, int NH, int NHpad, void* policy_out, void* value_out, bl_stream_t stream) {
+static int mlp_launch(const blmlp::Params& p, const blmlp::FinArgs* fin, bl_stream_t stream) {
     using namespace blmlp;
-    if (!obs || !w0 || !b0 || !wh || !bh || !policy_out || !value_out || M <= 0 || K0 <= 0 || D < 0 || NH < 2) return BL_EINVAL;
-    if (D > 0 && (!wb || !bb || !alphas)) return BL_EINVAL;
-    if (W % 128 != 0 || W < 128 || W > 1024 || K0pad % 64 != 0 || K0pad < K0 || K0pad > W || NHpad % 32 != 0 || NHpad < NH) return BL_ETOOBIG;
-    Params p{(const uint16_t*)obs, (const uint16_t*)w0, (const uint16_t*)b0, (const uint16_t*)wb, (const uint16_t*)bb, alphas,
-             (const uint16_t*)wh, (const uint16_t*)bh, (uint16_t*)policy_out, (uint16_t*)value_out, M, K0, K0pad, W, D, NH, NHpad};
+    const int W = p.W, NHpad = p.NHpad, M = p.M;
     // two activation buffers; the heads keep the neck in the first and stage split-K partials + outputs after it
+    // (+ 2 KiB of scratch per wave for the finish epilogue)
     const size_t buf = (size_t)32 * (W + 8) * 2;
-    const size_t staging = (size_t)(NHpad / 32) * 16 * 64 * 4 + (size_t)32 * NHpad * 2;
+    const size_t staging = (size_t)(NHpad / 32) * 16 * 64 * 4 + (size_t)32 * NHpad * 2 + (fin ? 8 * 4 * 128 * 4 : 0);
     const size_t lds = buf + (staging > buf ? staging : buf);
     if (lds > 160 * 1024) return BL_ETOOBIG;
     const dim3 grid((M + 31) / 32);
     hipStream_t hs = (hipStream_t)stream;
+    const FinArgs f = fin ? *fin : FinArgs{};
     // above the 64 KiB default the limit has to be raised per kernel (gfx950 has 160 KiB per CU)
-#define BL_MLP_LAUNCH(NT, PASSES, WAVES)                                                                               \
+#define BL_MLP_LAUNCH1(NT, PASSES, WAVES, FIN)                                                                         \
     {                                                                                                                  \
         static size_t raised = 65536;                                                                                  \
         if (lds > raised) {                                                                                            \
-            if (hipFuncSetAttribute((const void*)mlp_kernel<NT, PASSES, WAVES>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return BL_ELAUNCH; \
+            if (hipFuncSetAttribute((const void*)mlp_kernel<NT, PASSES, WAVES, FIN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return BL_ELAUNCH; \
             raised = lds;                                                                                              \
         }                                                                                                              \
-        hipLaunchKernelGGL((mlp_kernel<NT, PASSES, WAVES>), grid, dim3(WAVES * 64), lds, hs, p);                       \
+        hipLaunchKernelGGL((mlp_kernel<NT, PASSES, WAVES, FIN>), grid, dim3(WAVES * 64), lds, hs, p, f);               \
     }
+#define BL_MLP_LAUNCH(NT, PASSES, WAVES) { if (fin) BL_MLP_LAUNCH1(NT, PASSES, WAVES, true) else BL_MLP_LAUNCH1(NT, PASSES, WAVES, false) }
     // 8 waves (two per SIMD) from W = 256 up: while one wave waits for its weight fragments the other issues MFMAs
     switch (W / 128) {
-        case 1: BL_MLP_LAUNCH(1, 1, 4) break;
+        case 1: if (fin) return BL_ETOOBIG; BL_MLP_LAUNCH1(1, 1, 4, false) break;      // the epilogue assumes 8 waves
         case 2: BL_MLP_LAUNCH(1, 1, 8) break;
         case 4: BL_MLP_LAUNCH(2, 1, 8) break;
         case 6: BL_MLP_LAUNCH(1, 3, 8) break;
@@ -314,5 +487,44 @@ extern "C" int bl_mlp_forward_f16(const void* obs, int M, int K0, const void* w0
         default: return BL_ETOOBIG;
     }
 #undef BL_MLP_LAUNCH
+#undef BL_MLP_LAUNCH1
     return hipGetLastError() == hipSuccess ? BL_OK : BL_ELAUNCH;
+}
+
+static int mlp_check(const void* obs, int M, int K0, const void* w0, const void* b0, const void* wb, const void* bb,
+                     const float* alphas, const void* wh, const void* bh, int W, int D, int K0pad, int NH, int NHpad) {
+    if (!obs || !w0 || !b0 || !wh || !bh || M <= 0 || K0 <= 0 || D < 0 || NH < 2) return BL_EINVAL;
+    if (D > 0 && (!wb || !bb || !alphas)) return BL_EINVAL;
+    if (W % 128 != 0 || W < 128 || W > 1024 || K0pad % 64 != 0 || K0pad < K0 || K0pad > W || NHpad % 32 != 0 || NHpad < NH) return BL_ETOOBIG;
+    return BL_OK;
+}
+
+extern "C" int bl_mlp_forward_f16(const void* obs, int M, int K0, const void* w0, const void* b0, const void* wb,
+                                  const void* bb, const float* alphas, const void* wh, const void* bh, int W, int D,
+                                  int K0pad, int NH, int NHpad, void* policy_out, void* value_out, bl_stream_t stream) {
+    using namespace blmlp;
+    if (!policy_out || !value_out) return BL_EINVAL;
+    if (int rc = mlp_check(obs, M, K0, w0, b0, wb, bb, alphas, wh, bh, W, D, K0pad, NH, NHpad)) return rc;
+    Params p{(const uint16_t*)obs, (const uint16_t*)w0, (const uint16_t*)b0, (const uint16_t*)wb, (const uint16_t*)bb, alphas,
+             (const uint16_t*)wh, (const uint16_t*)bh, (uint16_t*)policy_out, (uint16_t*)value_out, M, K0, K0pad, W, D, NH, NHpad};
+    return mlp_launch(p, nullptr, stream);
+}
+
+extern "C" int bl_sim_infer_finish(const bl_search_t* s, int sim, const int16_t* leaves, const void* obs, const uint8_t* valid,
+                                   const int32_t* leaf_seats, const void* w0, const void* b0, const void* wb, const void* bb,
+                                   const float* alphas, const void* wh, const void* bh, int W, int D, int K0pad, int NHpad,
+                                   bl_stream_t stream) {
+    using namespace blmlp;
+    if (!s || !s->logits || !s->v || !s->w || !s->n || !s->rewards || !s->terminal || !s->qrange || !s->path || !leaves ||
+        !valid || !leaf_seats || s->B <= 0 || s->T <= 0 || s->boardsize <= 0 || sim < 1 || sim >= s->T) return BL_EINVAL;
+    const int A = s->boardsize * s->boardsize, M = s->B, K0 = 2 * A, NH = A + 1;
+    if (s->T > 64 || A > 128 || W < 256) return BL_ETOOBIG;     // the epilogue keeps a whole env in one wave's registers
+    if (int rc = mlp_check(obs, M, K0, w0, b0, wb, bb, alphas, wh, bh, W, D, K0pad, NH, NHpad)) return rc;
+    Params p{(const uint16_t*)obs, (const uint16_t*)w0, (const uint16_t*)b0, (const uint16_t*)wb, (const uint16_t*)bb, alphas,
+             (const uint16_t*)wh, (const uint16_t*)bh, nullptr, nullptr, M, K0, K0pad, W, D, NH, NHpad};
+    int np2 = 1; while (np2 < A) np2 *= 2;
+    const int Wsm = np2 < 64 ? np2 : 64;
+    FinArgs f{(uint16_t*)s->logits, (uint16_t*)s->v, (uint16_t*)s->w, s->n, (const uint16_t*)s->rewards, s->terminal, s->path,
+              s->qrange + (long)BLM_QSLOTS * BLM_QSTRIDE * (sim + 1), leaves, leaf_seats, valid, s->T, A, Wsm, np2 / Wsm};
+    return mlp_launch(p, &f, stream);
 }

@@ -89,7 +89,7 @@ class LeafWorlds:
 class MCTS:
 
     def __init__(self, world, n_nodes=64, c_puct=1 / 16, noise_eps=.25, alpha_scale=10, fused=None, rng=None,
-                 count=False, obs_half=False, qrange_sync=None):
+                 count=False, obs_half=False, qrange_sync=None, fuse_finish=True):
         """c_puct high: concentrates on prior; c_puct low: concentrates on value (mcts/__init__.py:29-33)."""
         from .. import hex as hexmod
         self.device = world.device
@@ -103,6 +103,8 @@ class MCTS:
         # optional callable(state_row) run after every backup on the q-range row the next descent will read, e.g.
         # parallel.allreduce_qrange: env shards on several GPUs then normalise q over ALL envs like one big batch
         self.qrange_sync = qrange_sync
+        # network forward + finish as one launch (bl_sim_infer_finish) when the network offers its packed weights
+        self.fuse_finish = fuse_finish
         # the fused kernels hard-code two-seat Hex; its one-player variants (hex.Solitaire) take the generic path
         self.fused = (isinstance(world, hexmod.Hex) and world.n_seats == 2) if fused is None else fused
         if self.fused and not isinstance(world, hexmod.Hex):
@@ -217,6 +219,15 @@ class MCTS:
                                                       self._obs.data_ptr(), self._valid.data_ptr(),
                                                       self._leaf_seats.data_ptr(), self.counters.data_ptr(), st))
             world = LeafWorlds(self, self._leaves, self._obs, self._valid, self._leaf_seats)
+            fp = network.fused_params() if (self.fuse_finish and hasattr(network, 'fused_params')) else None
+            if (fp is not None and self._obs.dtype == torch.half and self.n_nodes <= 64 and self.n_actions <= 128
+                    and fp['W'] >= 256 and fp['K0'] == 2 * self.n_actions and fp['NH'] == self.n_actions + 1):
+                # one launch: the network's Linears, its heads, the store, the backup and the next q range
+                _native.check(L.bl_sim_infer_finish(s, self.sim, self._leaves.data_ptr(), self._obs.data_ptr(),
+                                                    self._valid.data_ptr(), self._leaf_seats.data_ptr(), fp['w0'], fp['b0'],
+                                                    fp['wb'], fp['bb'], fp['al'], fp['wh'], fp['bh'], fp['W'], fp['D'],
+                                                    fp['K0pad'], fp['NHpad'], st))
+                return
             if hasattr(network, 'raw'):
                 # the network hands over its pre-head outputs; bl_sim_finish applies the heads, stores, backs up
                 with torch.no_grad(), torch.autocast('cuda', enabled=True):

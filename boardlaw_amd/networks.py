@@ -148,6 +148,19 @@ class Inference:
                 pk['bh'][:A].copy_(w[-3]); pk['bh'][A].copy_(w[-1][0])
         self._stamped = self._stamp()
 
+    def fused_params(self):
+        """Pointers and dims of the packed f16 weights for bl_sim_infer_finish, or None when the plan is not the fused
+        kernel's (then the caller uses raw() + bl_sim_finish)."""
+        if self._static is None:
+            self.refresh()
+        if not (self.fused and self._packed is not None):
+            return None
+        pk = self._packed
+        W, K0, K0pad, D, NH, NHpad = pk['dims']
+        return dict(w0=pk['w0'].data_ptr(), b0=self._static[0][1].data_ptr(), wb=pk['wb'].data_ptr(), bb=pk['bb'].data_ptr(),
+                    al=pk['al'].data_ptr(), wh=pk['wh'].data_ptr(), bh=pk['bh'].data_ptr(), W=W, D=D, K0=K0, K0pad=K0pad,
+                    NH=NH, NHpad=NHpad)
+
     def raw(self, worlds):
         from . import _native
         if self._static is None:

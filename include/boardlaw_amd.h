@@ -151,6 +151,16 @@ int bl_mlp_forward_f16(const void* obs /*f16 (M,K0)*/, int M, int K0, const void
                        const void* bb, const float* alphas /*(D) f32*/, const void* wh, const void* bh, int W, int D,
                        int K0pad, int NH, int NHpad, void* policy_out, void* value_out, bl_stream_t stream);
 
+/* bl_mlp_forward_f16 followed by bl_sim_finish as ONE launch: the workgroup that took 32 leaves through the network also
+ * applies the heads to them, stores logits/v, backs up along the recorded paths and publishes the next q range; what
+ * that step reads from the tree is requested at the start of the kernel and arrives under the GEMMs.  Same results as
+ * the two calls, bit for bit.  obs is the f16 observation bl_sim_expand wrote (s->obs_f16 == 1); M = s->B, K0 = 2A,
+ * NH = A + 1.  BL_ETOOBIG (use the two calls) unless s->T <= 64, A <= 128 and W >= 256. */
+int bl_sim_infer_finish(const bl_search_t* s, int sim, const int16_t* leaves /*(B)*/, const void* obs /*f16 (B,2A)*/,
+                        const uint8_t* valid /*(B,A)*/, const int32_t* leaf_seats /*(B)*/, const void* w0, const void* b0,
+                        const void* wb, const void* bb, const float* alphas, const void* wh, const void* bh, int W, int D,
+                        int K0pad, int NHpad, bl_stream_t stream);
+
 /* root distribution from qrange slot `sim` (call with sim = number of filled slots, i.e. MCTS.sim). */
 int bl_sim_root(const bl_search_t* s, int sim, void* probs_out /*f16 (B,A)*/, bl_stream_t stream);
 

@@ -677,3 +677,35 @@ def test_one_player_hex_variants():
     m = mcts(w, validation.RandomAgent(), n_nodes=8)
     assert not m.fused and m.stats.w.shape == (8, 8, 1) and (m.stats.n[:, 0] > 0).all()
     assert torch.allclose(m.root().logits.float().exp().sum(-1), torch.ones(8, device=DEV), atol=2e-2)
+
+
+@pytest.mark.parametrize('S,B,T,width,depth', [(9, 1000, 64, 512, 4), (5, 100, 16, 256, 2), (11, 33, 64, 512, 1), (3, 70, 8, 256, 3),
+                                                 (9, 4096, 64, 512, 4), (8, 5, 40, 1024, 2)])
+def test_infer_finish_in_one_launch_equals_two_launches(S, B, T, width, depth):
+    """bl_sim_infer_finish (network + heads + store + backup + next q range in one kernel) against bl_mlp_forward_f16
+    followed by bl_sim_finish: every array of the finished search identical."""
+    from boardlaw_amd import hex, networks
+    from boardlaw_amd.mcts import mcts
+    torch.manual_seed(S * 100 + T)
+    worlds = hex.Hex.initial(B, S, device=DEV)
+    for _ in range((S * S) // 3):
+        r = torch.rand(worlds.valid.shape, device=DEV) * worlds.valid
+        worlds, _ = worlds.step(r.argmax(-1), check=False)
+    net = networks.FCModel(worlds.obs_space, worlds.action_space, width=width, depth=depth).to(DEV)
+    inf = networks.Inference(net, fused=True)
+    assert inf.fused_params() is not None
+    out = []
+    for fuse in (True, False):
+        torch.manual_seed(5)                 # same noise and uniforms for both runs
+        out.append(mcts(worlds, inf, n_nodes=T, fuse_finish=fuse))
+    a, b = out
+    for x, y in [(a.tree.children, b.tree.children), (a.tree.parents, b.tree.parents), (a.tree.relation, b.tree.relation),
+                 (a.stats.n, b.stats.n), (a.stats.w, b.stats.w), (a.decisions.logits, b.decisions.logits),
+                 (a.decisions.v, b.decisions.v), (a.worlds.board, b.worlds.board)]:
+        assert np.array_equal(to_np(x), to_np(y))
+    # the q-range state is a set of slots whose element-wise max is the range: slot assignment differs, the range must not
+    from boardlaw_amd import _native
+    for row in range(1, T + 1):
+        assert torch.equal(_native.qrange_decode(a._qrange[row]), _native.qrange_decode(b._qrange[row]))
+    assert np.array_equal(bits16(a.root_probs()), bits16(b.root_probs()))
+    assert (to_np(a.stats.n)[:, 0] == 2 * (T - 1)).all()
