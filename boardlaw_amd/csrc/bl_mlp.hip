@@ -185,15 +185,40 @@ __global__ void __launch_bounds__(WAVES * 64) mlp_kernel(Params p, FinArgs f) {
     uint32_t frew[EPW], fw[EPW], fallW[EPW];
     float16v acc[NT];
     Ring<NT> rg;
-    gemm_prefetch<NT>(rg, p.w0, p.K0pad, wave * PASSES * NT, NT);   // weights first: their latency hides behind the staging
-    // stage the observation tile as 32-bit words (K0 is even: 2 planes per cell), zero-padding K0 -> K0pad and rows >= M
+    // stage the observation tile as 32-bit words (K0 is even: 2 planes per cell), zero-padding K0 -> K0pad and rows >= M.
+    // The observation loads are issued BEFORE the first weight fragments: vmcnt retires in order, so the other way round
+    // the staging barrier would also wait for the (cold, just evicted by the search kernel) weights.
     {
         const int wpr = p.K0pad >> 1, wvalid = p.K0 >> 1;           // words per staged row / per real row
         const uint32_t* src = (const uint32_t*)p.obs;               // row r starts at word r * K0 / 2 (K0 even)
         uint32_t* dst = (uint32_t*)(R0 + 32 * ld * par0);
-        for (int r = tid >> 5; r < 32; r += NTHREADS / 32)
-            for (int w = tid & 31; w < wpr; w += 32)
-                dst[r * (ld >> 1) + w] = (w < wvalid && row0 + r < p.M) ? src[(long)(row0 + r) * wvalid + w] : 0u;
+        constexpr int RPT = 32 / (NTHREADS / 32);                   // rows per thread: a thread owns column words w, w+32, ...
+        constexpr int WMAX = 4;                                     // ... up to 4 of them in registers (K0pad <= 256)
+        const int c = tid & 31, r_first = tid >> 5;
+        if (wpr <= 32 * WMAX) {
+            uint32_t st[RPT][WMAX];
+#pragma unroll
+            for (int i = 0; i < RPT; i++) {
+                const int r = r_first + i * (NTHREADS / 32);
+#pragma unroll
+                for (int k = 0; k < WMAX; k++) {
+                    const int w = c + 32 * k;
+                    st[i][k] = (w < wvalid && row0 + r < p.M) ? src[(long)(row0 + r) * wvalid + w] : 0u;
+                }
+            }
+            gemm_prefetch<NT>(rg, p.w0, p.K0pad, wave * PASSES * NT, NT);
+#pragma unroll
+            for (int i = 0; i < RPT; i++) {
+                const int r = r_first + i * (NTHREADS / 32);
+#pragma unroll
+                for (int k = 0; k < WMAX; k++) { const int w = c + 32 * k; if (w < wpr) dst[r * (ld >> 1) + w] = st[i][k]; }
+            }
+        } else {
+            gemm_prefetch<NT>(rg, p.w0, p.K0pad, wave * PASSES * NT, NT);
+            for (int r = r_first; r < 32; r += NTHREADS / 32)
+                for (int w = c; w < wpr; w += 32)
+                    dst[r * (ld >> 1) + w] = (w < wvalid && row0 + r < p.M) ? src[(long)(row0 + r) * wvalid + w] : 0u;
+        }
     }
     __syncthreads();
     if constexpr (FINISH) {
