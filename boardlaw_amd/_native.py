@@ -32,6 +32,7 @@ SYMBOLS = {
     'bl_mcts_backup': (_i, [_vp] * 7 + [_i] * 3 + [_vp]),
     'bl_hex_step': (_i, [_vp] * 4 + [_i, _i, _vp]),
     'bl_hex_observe': (_i, [_vp] * 3 + [_i, _i, _vp]),
+    'bl_hex_world_step': (_i, [_vp] * 3 + [_i] + [_vp] * 4 + [_i, _i, _vp]),
     'bl_sim_expand': (_i, [ctypes.POINTER(Search), _i] + [_vp] * 5 + [_vp]),
     'bl_sim_expand_counted': (_i, [ctypes.POINTER(Search), _i] + [_vp] * 6 + [_vp]),
     'bl_sim_backup': (_i, [ctypes.POINTER(Search), _i, _vp, _vp, _i, _vp, _i, _vp]),

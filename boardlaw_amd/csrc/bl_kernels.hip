@@ -701,6 +701,34 @@ __global__ void __launch_bounds__(BL_WAVE) hex_step_kernel(uint8_t* board, const
     }
 }
 
+// Hex.step as one launch (hex/__init__.py:161-195 with reset=True): clone the board, step it, terminal = any reward > 0,
+// wipe finished boards, pass the move to the other seat (seat 0 after a finished game).
+template <int G>
+__global__ void __launch_bounds__(BL_WAVE) hex_world_step_kernel(const uint8_t* board_in, const int32_t* seats_in, const void* actions,
+                                                                 int actions_i64, uint8_t* board_out, int32_t* seats_out,
+                                                                 float* rewards, uint8_t* terminal, int B, int S) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int A = S * S, grp = threadIdx.x / G, gl = threadIdx.x % G;
+    const int b = blockIdx.x * (BL_WAVE / G) + grp;
+    const bool go = b < B;
+    uint8_t* cells = (uint8_t*)smem + (size_t)grp * ((A + 15) & ~15);
+    const uint8_t* src = board_in + (long)b * A;
+    if (go) for (int a = gl; a < A; a += G) cells[a] = src[a];
+    int seat = 0, action = 0;
+    if (go) { seat = seats_in[b]; action = actions_i64 ? (int)((const long long*)actions)[b] : ((const int32_t*)actions)[b]; }
+    __syncthreads();
+    const int win = hex_step_group<G>(cells, S, seat, action, go, gl);
+    if (go) {
+        uint8_t* dst = board_out + (long)b * A;
+        for (int a = gl; a < A; a += G) dst[a] = win ? (uint8_t)0 : cells[a];
+        if (gl == 0) {
+            rewards[2 * b] = (float)win; rewards[2 * b + 1] = (float)(-win);
+            terminal[b] = win != 0;
+            seats_out[b] = win ? 0 : 1 - seat;
+        }
+    }
+}
+
 // observe, cuda.cu:154-195: mover sees itself in channel 0, playing top-to-bottom.
 __device__ __forceinline__ int color_of(int c) { return (c == BLACK || c == TOP || c == BOT) ? 0 : ((c == WHITE || c == LEFT || c == RIGHT) ? 1 : 2); }
 
@@ -1169,6 +1197,21 @@ int bl_hex_step(uint8_t* board, const int32_t* seats, const int32_t* actions, fl
     const int blocks = (B + 64 / G - 1) / (64 / G);
     hipLaunchKernelGGL((hex_step_kernel<G>), dim3(blocks), dim3(64), (size_t)((S * S + 15) & ~15) * (64 / G),
                        (hipStream_t)stream, board, seats, actions, rewards, B, S);
+    return check_launch();
+}
+
+int bl_hex_world_step(const uint8_t* board_in, const int32_t* seats_in, const void* actions, int actions_i64,
+                      uint8_t* board_out, int32_t* seats_out, float* rewards, uint8_t* terminal, int B, int S,
+                      bl_stream_t stream) {
+    if (!board_in || !seats_in || !actions || !board_out || !seats_out || !rewards || !terminal || B <= 0 || S <= 0) return BL_EINVAL;
+    if (S > 32) return BL_ETOOBIG;
+    const int A = S * S, G = pick_group(B, A);
+    const int blocks = (B + 64 / G - 1) / (64 / G);
+    const size_t lds = (size_t)((A + 15) & ~15) * (64 / G);
+#define CALL(g) hipLaunchKernelGGL((hex_world_step_kernel<g>), dim3(blocks), dim3(64), lds, (hipStream_t)stream, board_in, seats_in, \
+                                   actions, actions_i64, board_out, seats_out, rewards, terminal, B, S)
+    switch (G) { case 8: CALL(8); break; case 16: CALL(16); break; case 32: CALL(32); break; default: CALL(64); break; }
+#undef CALL
     return check_launch();
 }
 

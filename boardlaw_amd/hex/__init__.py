@@ -59,6 +59,10 @@ class Hex(arrdict.namedarrtuple('Hex', fields=('board', 'seats'))):
         if check:
             assert self.valid.gather(1, actions[:, None].long()).squeeze(-1).all()
 
+        if reset and self.seats.dtype == torch.int32 and self.board.is_contiguous() and self.seats.is_contiguous():
+            # the whole transition as one launch (bl_hex_world_step); same results as the steps below
+            new_board, new_seats, rewards, terminal = cuda.world_step(self.board, self.seats, actions)
+            return type(self)(board=new_board, seats=new_seats), arrdict.arrdict(terminal=terminal, rewards=rewards)
         new_board = self.board.clone()
         rewards = cuda.step(new_board, self.seats.int(), actions.int())
         if reset:

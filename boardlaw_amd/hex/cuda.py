@@ -29,6 +29,26 @@ def step(board, seats, actions):
     return rewards
 
 
+def world_step(board, seats, actions):
+    """Hex.step with reset=True in one launch: (new_board u8 (B,S,S), new_seats i32 (B,), rewards f32 (B,2), terminal bool (B,));
+    the inputs are left untouched.  actions i32 or i64."""
+    _check(board, torch.uint8, 3, 'board'); _check(seats, torch.int32, 1, 'seats')
+    if actions.dtype not in (torch.int32, torch.int64) or not actions.is_contiguous():
+        actions = actions.long().contiguous()
+    dev = _native.require_device(board, seats, actions)
+    B, S, _ = board.shape
+    new_board, new_seats = torch.empty_like(board), torch.empty_like(seats)
+    rewards = torch.empty((B, 2), dtype=torch.float32, device=dev)
+    terminal = torch.empty((B,), dtype=torch.bool, device=dev)
+    if B:
+        with torch.cuda.device(dev):
+            _native.check(_native.lib().bl_hex_world_step(board.data_ptr(), seats.data_ptr(), actions.data_ptr(),
+                                                          int(actions.dtype == torch.int64), new_board.data_ptr(),
+                                                          new_seats.data_ptr(), rewards.data_ptr(), terminal.data_ptr(), B, S,
+                                                          _native.stream(dev)))
+    return new_board, new_seats, rewards, terminal
+
+
 def observe(board, seats):
     """board (..., S, S) u8, seats (...) any int -> obs (..., S, S, 2) f32."""
     S = board.shape[-1]

@@ -81,6 +81,14 @@ int bl_mcts_backup(const void* v /*f16 (B,T,S)*/, void* w /*f16 (B,T,S)*/, int16
 int bl_hex_step(uint8_t* board, const int32_t* seats, const int32_t* actions, float* rewards_out /*(B,2)*/,
                 int B, int boardsize, bl_stream_t stream);
 
+/* Hex.step(actions) with reset=True as one launch (boardlaw/hex/__init__.py:161-195): board_out = step(clone(board_in));
+ * rewards (B,2) f32; terminal = any reward > 0; finished boards are wiped and handed to seat 0, the others to the other
+ * seat.  actions: i32 (actions_i64 = 0) or i64 (1) flat cell indices in the mover's frame.  No validity checks (the
+ * Python caller keeps the reference's asserts when asked to). */
+int bl_hex_world_step(const uint8_t* board_in, const int32_t* seats_in, const void* actions, int actions_i64,
+                      uint8_t* board_out, int32_t* seats_out, float* rewards_out, uint8_t* terminal_out, int B, int S,
+                      bl_stream_t stream);
+
 /* ---- hexcuda.observe(board, seats) -> (B,S,S,2) f32   (hex/cpp/wrappers.cpp:28-34, cuda.cu:154-217) -------------
  * Leading dims are flattened by the caller.  obs_out is fully written. */
 int bl_hex_observe(const uint8_t* board, const int32_t* seats, float* obs_out, int B, int boardsize, bl_stream_t stream);

@@ -709,3 +709,29 @@ def test_infer_finish_in_one_launch_equals_two_launches(S, B, T, width, depth):
         assert torch.equal(_native.qrange_decode(a._qrange[row]), _native.qrange_decode(b._qrange[row]))
     assert np.array_equal(bits16(a.root_probs()), bits16(b.root_probs()))
     assert (to_np(a.stats.n)[:, 0] == 2 * (T - 1)).all()
+
+
+@pytest.mark.parametrize('S,B', [(9, 4096), (3, 50), (13, 257), (32, 9), (1, 4)])
+def test_world_step_in_one_launch_equals_the_composed_step(S, B):
+    """bl_hex_world_step (Hex.step with reset=True as one kernel) against clone + bl_hex_step + the reference's mask
+    arithmetic (hex/__init__.py:181-190), along random games with resets; i32 and i64 actions."""
+    from boardlaw_amd import hex
+    from boardlaw_amd.hex import cuda as hcuda
+    torch.manual_seed(S)
+    w = hex.Hex.initial(B, S, device=DEV)
+    finished = 0
+    for t in range(3 * S * S // 2 + 2):
+        a = (torch.rand(w.valid.shape, device=DEV) * w.valid).argmax(-1)
+        board = w.board.clone()
+        rewards = hcuda.step(board, w.seats.int(), a.int())
+        terminal = (rewards > 0).any(-1)
+        board[terminal] = 0
+        seats = 1 - w.seats
+        seats[terminal] = 0
+        nb, ns, nr, nt = hcuda.world_step(w.board, w.seats, a if t % 2 else a.int())
+        assert torch.equal(nb, board) and torch.equal(ns, seats) and torch.equal(nr, rewards) and torch.equal(nt, terminal)
+        w2, tr = w.step(a)                                   # the public entry point takes the same route
+        assert torch.equal(w2.board, board) and torch.equal(tr.terminal, terminal) and w2.seats.dtype == torch.int32
+        finished += int(terminal.sum())
+        w = w2
+    assert finished > 0
