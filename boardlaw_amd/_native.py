@@ -41,6 +41,7 @@ SYMBOLS = {
     'bl_mlp_forward_f16': (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     'bl_sim_infer_finish': (_i, [ctypes.POINTER(Search), _i] + [_vp] * 11 + [_i] * 4 + [_vp]),
     'bl_sim_root': (_i, [ctypes.POINTER(Search), _i, _vp, _vp]),
+    'bl_sim_n_leaves': (_i, [ctypes.POINTER(Search), _vp, _vp]),
     'bl_sim_init': (_i, [ctypes.POINTER(Search), _vp, _vp, _vp]),
 }
 

@@ -1035,6 +1035,23 @@ __global__ void sim_init_qrange_kernel(Search s) {
     s.qrange[BL_QWORDS * 1 + 1] = enc(0.f);
 }
 
+// MCTS.n_leaves (mcts/__init__.py:151-152): nodes that exist (parents != -1) and have no child.  A node has a child
+// exactly when some node names it as its parent, so the (B,T) parents array suffices.  One wave per env; LDS flags.
+__global__ void __launch_bounds__(BL_WAVE) sim_n_leaves_kernel(const int16_t* parents, long long* out, int T) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    uint8_t* has_child = (uint8_t*)smem;
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const int16_t* p = parents + (long)b * T;
+    for (int t = lane; t < T; t += BL_WAVE) has_child[t] = 0;
+    __syncthreads();
+    for (int t = lane; t < T; t += BL_WAVE) { const int q = p[t]; if (q >= 0) has_child[q] = 1; }
+    __syncthreads();
+    int count = 0;
+    for (int t = lane; t < T; t += BL_WAVE) count += (p[t] != -1) && !has_child[t];
+    count = wave_sum_i32(count);
+    if (lane == 0) out[b] = count;
+}
+
 __global__ void __launch_bounds__(256) zero_words_kernel(uint32_t* p, int n) {
     for (int i = threadIdx.x; i < n; i += blockDim.x) p[i] = 0;
 }
@@ -1323,6 +1340,13 @@ int bl_sim_root(const bl_search_t* s, int sim, void* probs, bl_stream_t stream) 
                                       (hipStream_t)stream, m, (uint16_t*)probs)
     BL_DISPATCH_GK(G, K, CALL)
 #undef CALL
+    return check_launch();
+}
+
+int bl_sim_n_leaves(const bl_search_t* s, long long* out, bl_stream_t stream) {
+    if (int rc = search_check(s)) return rc;
+    if (!out) return BL_EINVAL;
+    hipLaunchKernelGGL(sim_n_leaves_kernel, dim3(s->B), dim3(64), (size_t)((s->T + 15) & ~15), (hipStream_t)stream, s->parents, out, s->T);
     return check_launch();
 }
 

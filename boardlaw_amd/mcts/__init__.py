@@ -283,6 +283,11 @@ class MCTS:
         """Nodes that exist and have no child (mcts/__init__.py:151-152: `(children == -1).all(-1) & (parents != -1)`).
         A node has a child exactly when some node names it as its parent, so this reads the two (B,T) arrays instead of
         the (B,T,A) children array (42 MB at 9x9/4096/64)."""
+        if self.fused:
+            out = torch.empty((self.n_envs,), dtype=torch.long, device=self.device)
+            with torch.cuda.device(self.device):
+                _native.check(_native.lib().bl_sim_n_leaves(ctypes.byref(self._search), out.data_ptr(), _native.stream(self.device)))
+            return out
         parents = self.tree.parents
         exists = parents != -1
         n_children = torch.zeros(parents.shape, dtype=torch.int32, device=parents.device)
@@ -318,17 +323,19 @@ class MCTSAgent:
         self.graph = graph
         self._graphs = {}
 
-    def _move(self, world, eval, kwargs):
+    def _move(self, world, eval, kwargs, clone=True):
         m = mcts(world, self.network, **{**self.kwargs, **kwargs})
         r = m.root()
         actions = r.logits.argmax(-1) if eval else m.rng.categorical(r.logits.float())
-        return arrdict.arrdict(
+        d = arrdict.arrdict(
             logits=r.logits,
             prior=r.prior,
             n_sims=torch.full_like(m.envs, m.sim + 1),     # the reference's off-by-one, kept
             n_leaves=m.n_leaves(),
             v=r.v,
-            actions=actions).clone()
+            actions=actions)
+        # prior and v are views of the tree: detach them from it, unless the caller (a graph replayer) clones anyway
+        return d.clone() if clone else d
 
     def __call__(self, world, value=True, eval=False, **kwargs):
         if not self.graph or kwargs or world.device.type != 'cuda':
@@ -378,7 +385,7 @@ class _GraphedMove:
 
         def run():
             w = kind(board=self.board, seats=self.seats)
-            d = agent._move(w, eval, {})
+            d = agent._move(w, eval, {}, clone=False)      # __call__ clones the replay's outputs
             if not step:
                 return d
             new_world, transition = w.step(d.actions, check=False)

@@ -169,6 +169,9 @@ int bl_sim_infer_finish(const bl_search_t* s, int sim, const int16_t* leaves /*(
                         const void* wb, const void* bb, const float* alphas, const void* wh, const void* bh, int W, int D,
                         int K0pad, int NHpad, bl_stream_t stream);
 
+/* MCTS.n_leaves (mcts/__init__.py:151-152): per env, nodes with parents != -1 that no node names as its parent. */
+int bl_sim_n_leaves(const bl_search_t* s, long long* out /*i64 (B)*/, bl_stream_t stream);
+
 /* root distribution from qrange slot `sim` (call with sim = number of filled slots, i.e. MCTS.sim). */
 int bl_sim_root(const bl_search_t* s, int sim, void* probs_out /*f16 (B,A)*/, bl_stream_t stream);
 
