@@ -994,6 +994,75 @@ __global__ void __launch_bounds__(256) rezero_relu_kernel(const uint16_t* x, con
     }
 }
 
+// The same ReZero tail in fp32 (the root evaluation runs outside autocast, mcts/__init__.py:72-76): x_out = x + alpha*y
+// with the product and the sum rounded separately, as torch's mul and add kernels do, plus relu(x_out).
+__global__ void __launch_bounds__(256) rezero_relu_f32_kernel(const float* x, const float* y, const float* alpha,
+                                                             float* x_out, float* relu_out, long n) {
+    const float al = *alpha;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const float o = x[i] + al * y[i];
+        x_out[i] = o;
+        relu_out[i] = (o < 0.f) ? 0.f : o;          // keeps NaN, like torch's relu
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// bl_sim_plant_root: what MCTS.initialize does with the root network's fp32 pre-head outputs (mcts/__init__.py:72-80,
+// 13-24; heads.py:101-104,122-142), one wave per env:
+//   logits = log_softmax(masked_fill(policy_raw, ~valid, -inf))            torch's persistent-softmax operation order
+//   draw[~valid] = 0; draw /= draw.sum();  logits = log(exp(logits)*(1-eps) + draw*eps)      dirichlet_noise
+//   v = scatter_values(tanh(value_raw), seats)
+//   decisions.logits[:, 0] = logits.half(); decisions.v[:, 0] = v.half()
+// ------------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(BL_WAVE) sim_plant_root_kernel(Search s, const float* policy_raw, const float* value_raw,
+                                                                const uint8_t* valid, const int32_t* seats, const float* draw,
+                                                                float eps, int W, int iters) {
+    const int S = s.S, A = S * S, T = s.T;
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const long envbase = (long)b * T;
+    if (lane < W) {
+        float e[16], d[16];
+        float mx = -INFINITY, dsum = 0.f;
+#pragma unroll
+        for (int it = 0; it < 16; it++) {
+            e[it] = -INFINITY; d[it] = 0.f;
+            if (it < iters) {
+                const int a = lane + it * W;
+                if (a < A) {
+                    const bool ok = valid[(long)b * A + a];
+                    e[it] = ok ? policy_raw[(long)b * A + a] : -INFINITY;
+                    if (draw) d[it] = ok ? draw[(long)b * A + a] : 0.f;
+                }
+                mx = (it == 0) ? e[0] : ((mx > e[it]) ? mx : e[it]);
+                dsum += d[it];
+            }
+        }
+        for (int off = W / 2; off > 0; off /= 2) { const float o = __shfl_xor(mx, off, W); mx = (mx < o) ? o : mx; }
+        float sum = 0.f;
+#pragma unroll
+        for (int it = 0; it < 16; it++) if (it < iters) sum += expf(e[it] - mx);
+        for (int off = W / 2; off > 0; off /= 2) { sum = sum + __shfl_xor(sum, off, W); dsum = dsum + __shfl_xor(dsum, off, W); }
+        const float lsum = logf(sum);
+        const float keep = 1.f - eps;
+        uint16_t* dst = s.logits + envbase * A;          // node 0
+#pragma unroll
+        for (int it = 0; it < 16; it++) {
+            const int a = lane + it * W;
+            if (it < iters && a < A) {
+                float l = e[it] - mx - lsum;
+                if (draw) l = logf(expf(l) * keep + (d[it] / dsum) * eps);
+                dst[a] = f2h(l);
+            }
+        }
+    }
+    if (lane == 0) {
+        const float tv = tanhf(value_raw[b]);
+        const int mover = seats[b];
+        s.v[envbase * 2 + mover] = f2h(tv);
+        s.v[envbase * 2 + 1 - mover] = f2h(-tv);
+    }
+}
+
 // Fills nbytes at p (16-B aligned, as torch allocations are) with a repeating 16-bit pattern; whole grid cooperates.
 __device__ __forceinline__ void grid_fill(void* p, size_t nbytes, uint16_t pat) {
     const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x, nth = (size_t)gridDim.x * blockDim.x;
@@ -1323,6 +1392,28 @@ int bl_rezero_relu_f16(const void* x, const void* y, const float* alpha, void* x
     long blocks = (n8 + 255) / 256; if (blocks > 2048) blocks = 2048; if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(rezero_relu_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)x,
                        (const uint16_t*)y, alpha, (uint16_t*)x_out, (uint16_t*)relu_out, n8, n);
+    return check_launch();
+}
+
+int bl_rezero_relu_f32(const float* x, const float* y, const float* alpha, float* x_out, float* relu_out, long n,
+                       bl_stream_t stream) {
+    if (!x || !y || !alpha || !x_out || !relu_out || n <= 0) return BL_EINVAL;
+    long blocks = (n + 255) / 256; if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(rezero_relu_f32_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, y, alpha, x_out, relu_out, n);
+    return check_launch();
+}
+
+int bl_sim_plant_root(const bl_search_t* s, const float* policy_raw, const float* value_raw, const uint8_t* valid,
+                      const int32_t* seats, const float* draw, float eps, bl_stream_t stream) {
+    int rc = search_check(s);
+    if (rc) return rc;
+    if (!policy_raw || !value_raw || !valid || !seats) return BL_EINVAL;
+    const int A = s->boardsize * s->boardsize;
+    int np2 = 1; while (np2 < A) np2 *= 2;
+    const int W = np2 < 64 ? np2 : 64, iters = np2 / W;
+    if (iters > 16) return BL_ETOOBIG;
+    hipLaunchKernelGGL(sim_plant_root_kernel, dim3(s->B), dim3(64), 0, (hipStream_t)stream, to_search(s), policy_raw, value_raw,
+                       valid, seats, draw, eps, W, iters);
     return check_launch();
 }
 

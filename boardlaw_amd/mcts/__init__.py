@@ -157,6 +157,21 @@ class MCTS:
     # ------------------------------------------------------------------ mcts/__init__.py:72-80
     def initialize(self, network):
         world = self._root_world if self.fused else self.worlds[:, 0]
+        if (self.fused and self.fuse_finish and hasattr(network, 'root_raw') and world.board.is_cuda
+                and type(getattr(network.model, 'policy', None)).__name__ == 'MaskedOutput'):
+            # the network's Linears in fp32, then heads + dirichlet noise + store as ONE launch (bl_sim_plant_root)
+            assert self.sim == 0
+            policy_raw, value_raw = network.root_raw(world)
+            policy_raw, value_raw = policy_raw.float().contiguous(), value_raw.float().contiguous()
+            valid = world.valid.contiguous()
+            alpha = torch.full((self.n_actions,), self.alpha_scale / self.n_actions, dtype=torch.float, device=self.device)
+            draw = self.rng.dirichlet(alpha, (self.n_envs,)).float().contiguous()      # mcts/__init__.py:16-18
+            with torch.cuda.device(self.device):
+                _native.check(_native.lib().bl_sim_plant_root(ctypes.byref(self._search), policy_raw.data_ptr(), value_raw.data_ptr(),
+                                                              valid.data_ptr(), world.seats.int().contiguous().data_ptr(),
+                                                              draw.data_ptr(), float(self.noise_eps), _native.stream(self.device)))
+            self.sim = 1
+            return
         with torch.no_grad():
             decisions = network(world)
         self.plant_root(dirichlet_noise(decisions.logits, world.valid, self.noise_eps, self.alpha_scale, self.rng), decisions.v)

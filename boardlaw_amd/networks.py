@@ -148,6 +148,28 @@ class Inference:
                 pk['bh'][:A].copy_(w[-3]); pk['bh'][A].copy_(w[-1][0])
         self._stamped = self._stamp()
 
+    def root_raw(self, worlds):
+        """fp32 pre-head outputs for the root evaluation (MCTS.initialize runs the network outside autocast,
+        mcts/__init__.py:72-76): the module's own fp32 parameters and torch's GEMMs, with each block's alpha*y, x + .
+        and the next relu issued as one kernel (bl_rezero_relu_f32; same two roundings as torch's mul and add).
+        Bit-identical to FCModel.raw in fp32 (tests/test_gpu_parity.py::test_root_plan_matches_module)."""
+        from . import _native
+        m = self.model
+        blocks = list(m.body)
+        obs = worlds.obs
+        x0 = obs.reshape(obs.shape[0], -1).float().contiguous()
+        L, st = _native.lib(), _native.stream(x0.device)
+        with torch.no_grad():
+            x = F.linear(x0, blocks[0].weight, blocks[0].bias)
+            r = F.relu(x)
+            for blk in blocks[1:]:
+                y = F.linear(r, blk.weight, blk.bias)
+                x_new, r = torch.empty_like(x), torch.empty_like(x)
+                _native.check(L.bl_rezero_relu_f32(x.data_ptr(), y.data_ptr(), getattr(blk, 'α').data_ptr(), x_new.data_ptr(),
+                                                   r.data_ptr(), x.numel(), st))
+                x = x_new
+            return F.linear(x, m.policy.core.weight, m.policy.core.bias), F.linear(x, m.value.core.weight, m.value.core.bias).squeeze(-1)
+
     def fused_params(self):
         """Pointers and dims of the packed f16 weights for bl_sim_infer_finish, or None when the plan is not the fused
         kernel's (then the caller uses raw() + bl_sim_finish)."""

@@ -169,6 +169,18 @@ int bl_sim_infer_finish(const bl_search_t* s, int sim, const int16_t* leaves /*(
                         const void* wb, const void* bb, const float* alphas, const void* wh, const void* bh, int W, int D,
                         int K0pad, int NHpad, bl_stream_t stream);
 
+/* The ReZero tail in fp32 for the root evaluation (which runs outside autocast): x_out = x + alpha*y, product and sum
+ * rounded separately like torch's mul and add; relu_out = relu(x_out). */
+int bl_rezero_relu_f32(const float* x, const float* y, const float* alpha, float* x_out, float* relu_out, long n,
+                       bl_stream_t stream);
+
+/* MCTS.initialize after the root network's Linears (mcts/__init__.py:72-80, 13-24; heads.py:101-104,122-142) in one
+ * launch: masked log-softmax of policy_raw (B,A) f32, dirichlet noise from `draw` (B,A) f32 -- zeroed where invalid,
+ * renormalised, mixed in as log(exp(l)(1-eps) + eps*draw); draw may be NULL: no noise step at all -- tanh(value_raw)
+ * scattered by seat, both rounded to f16 into node 0 of s->logits / s->v.  The caller then sets its sim counter to 1. */
+int bl_sim_plant_root(const bl_search_t* s, const float* policy_raw, const float* value_raw /*(B)*/, const uint8_t* valid,
+                      const int32_t* seats /*(B)*/, const float* draw, float eps, bl_stream_t stream);
+
 /* MCTS.n_leaves (mcts/__init__.py:151-152): per env, nodes with parents != -1 that no node names as its parent. */
 int bl_sim_n_leaves(const bl_search_t* s, long long* out /*i64 (B)*/, bl_stream_t stream);
 

@@ -735,3 +735,55 @@ def test_world_step_in_one_launch_equals_the_composed_step(S, B):
         finished += int(terminal.sum())
         w = w2
     assert finished > 0
+
+
+def test_root_plan_matches_module():
+    """Inference.root_raw (fp32 GEMMs + bl_rezero_relu_f32) against FCModel.raw in fp32: identical bits."""
+    from boardlaw_amd import hex, networks
+    torch.manual_seed(3)
+    worlds = hex.Hex.initial(300, 9, device=DEV)
+    net = networks.FCModel(worlds.obs_space, worlds.action_space, width=256, depth=3).to(DEV)
+    with torch.no_grad():
+        for blk in list(net.body)[1:]:
+            getattr(blk, 'α').fill_(float(torch.randn(()) * 0.7))
+        p0, v0 = net.raw(worlds)
+    p1, v1 = networks.Inference(net, fused=True).root_raw(worlds)
+    assert p1.dtype == torch.float and torch.equal(p0, p1) and torch.equal(v0, v1)
+
+
+class _FixedDraw:
+    """rng stub: hands the same Dirichlet draw to both code paths."""
+    def __init__(self, draw): self.draw = draw
+    def dirichlet(self, alpha, shape): return self.draw.clone()
+    def rand_like(self, x): return torch.rand_like(x)
+
+
+@pytest.mark.parametrize('S,B,eps', [(9, 500, .25), (5, 77, .25), (13, 40, .1), (3, 9, 0.)])
+def test_plant_root_in_one_launch_matches_the_composition(S, B, eps):
+    """bl_sim_plant_root (masked log-softmax + dirichlet mixing + tanh/scatter + f16 store in one kernel) against
+    network(world) -> dirichlet_noise -> plant_root.  The kernel sums the masked draw in its own order, so: every stored
+    value within 1 f16 ulp, and all but a handful identical."""
+    from boardlaw_amd import hex, networks
+    from boardlaw_amd.mcts import MCTS
+    torch.manual_seed(S)
+    worlds = hex.Hex.initial(B, S, device=DEV)
+    for _ in range(S):
+        worlds, _ = worlds.step((torch.rand(worlds.valid.shape, device=DEV) * worlds.valid).argmax(-1), check=False)
+    net = networks.FCModel(worlds.obs_space, worlds.action_space, width=128, depth=2).to(DEV)
+    inf = networks.Inference(net, fused=True)
+    draw = torch.distributions.Dirichlet(torch.full((S * S,), 10 / (S * S), device=DEV)).sample((B,))
+    a = MCTS(worlds, n_nodes=4, noise_eps=eps, rng=_FixedDraw(draw), obs_half=True)
+    a.initialize(inf)                                  # one launch
+    b = MCTS(worlds, n_nodes=4, noise_eps=eps, rng=_FixedDraw(draw), obs_half=True, fuse_finish=False)
+    b.initialize(inf)                                  # network(world) + dirichlet_noise + plant_root
+    assert a.sim == b.sim == 1
+    la, lb = a.decisions.logits[:, 0].float(), b.decisions.logits[:, 0].float()
+    assert torch.equal(torch.isinf(la), torch.isinf(lb))
+    fin = ~torch.isinf(la)
+    assert ((la - lb)[fin].abs() <= 2**-10 * lb[fin].abs().clamp(min=2**-14)).all()
+    assert (bits16_t(a.decisions.logits[:, 0]) == bits16_t(b.decisions.logits[:, 0])).float().mean() > 0.995
+    assert torch.equal(a.decisions.v[:, 0], b.decisions.v[:, 0])
+
+
+def bits16_t(t):
+    return t.contiguous().view(torch.int16)
