@@ -1087,14 +1087,30 @@ __global__ void __launch_bounds__(256) sim_init_kernel(Search s, const uint8_t* 
     grid_fill(s.rewards, B * T * 2 * 2, 0);
     grid_fill(s.terminal, B * T, 0);
     grid_fill(s.qrange, (T + 1) * (size_t)BL_QWORDS * sizeof(uint32_t), 0);
-    const long total = (long)(B * T * A);
-    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
-        const long node = idx / (long)A;
-        const int a = (int)(idx - node * (long)A);
-        const long b = node / (long)T;
-        s.boards[idx] = root_board[b * A + a];
-        if (a == 0) s.seats[node] = root_seats[b];
+}
+
+// worlds = stack([world] * T) (mcts/__init__.py:62): every node slot of env b starts as a copy of the root board and
+// seat.  One workgroup per env: the T*A bytes of its slots are the root board repeated, written as 32-bit words.
+__global__ void __launch_bounds__(256) sim_init_worlds_kernel(Search s, const uint8_t* root_board, const int32_t* root_seats) {
+    __shared__ uint8_t root[1024];
+    const int b = blockIdx.x, T = s.T, A = s.S * s.S;
+    for (int a = threadIdx.x; a < A; a += blockDim.x) root[a] = root_board[(long)b * A + a];
+    __syncthreads();
+    const long bytes = (long)T * A;
+    uint8_t* dst = s.boards + (long)b * bytes;            // torch allocations are >= 16-B aligned and T*A*b keeps 1-B steps:
+    const long head = (4 - ((uintptr_t)dst & 3)) & 3;     // bytes before the first aligned word of this env's block
+    for (long i = threadIdx.x; i < head && i < bytes; i += blockDim.x) dst[i] = root[i % A];
+    const long words = bytes > head ? (bytes - head) / 4 : 0;
+    for (long k = threadIdx.x; k < words; k += blockDim.x) {
+        int o = (int)((head + 4 * k) % A);
+        uint32_t v = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) { v |= (uint32_t)root[o] << (8 * j); o = (o + 1 == A) ? 0 : o + 1; }
+        *(uint32_t*)(dst + head + 4 * k) = v;
     }
+    for (long i = head + 4 * words + threadIdx.x; i < bytes; i += blockDim.x) dst[i] = root[i % A];
+    const int seat = root_seats[b];
+    for (int t = threadIdx.x; t < T; t += blockDim.x) s.seats[(long)b * T + t] = seat;
 }
 
 // descend #1 sees the untouched stats: every q is 0/1e-4 = 0, so its range is {0, 0}.  Separate launch: it must land
@@ -1447,6 +1463,7 @@ int bl_sim_init(const bl_search_t* s, const uint8_t* root_board, const int32_t* 
     if (!root_board || !root_seats) return BL_EINVAL;
     hipStream_t hs = (hipStream_t)stream;
     hipLaunchKernelGGL(sim_init_kernel, dim3(2048), dim3(256), 0, hs, to_search(s), root_board, root_seats);
+    hipLaunchKernelGGL(sim_init_worlds_kernel, dim3(s->B), dim3(256), 0, hs, to_search(s), root_board, root_seats);
     hipLaunchKernelGGL(sim_init_qrange_kernel, dim3(1), dim3(1), 0, hs, to_search(s));
     return check_launch();
 }
