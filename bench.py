@@ -101,6 +101,43 @@ def cpu_baseline(seconds_budget=25.0):
     return run_cpu_search(BOARD, NODES, WIDTH, DEPTH, seconds_budget)
 
 
+def respawn_per_gpu(args):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: re-executes itself as N ranks, one process per GPU
+    (the reference's model: boardlaw/main.py:202-209, rebar/parallel.py:28-36), under torch.distributed.run on 127.0.0.1.
+    Under a launcher (WORLD_SIZE set) the world size must equal --gpus."""
+    world = os.environ.get('WORLD_SIZE')
+    if world is not None:
+        if int(world) != args.gpus:
+            raise SystemExit(f'bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks')
+        return
+    if args.gpus > 1:
+        import socket
+        with socket.socket() as sock:
+            sock.bind(('127.0.0.1', 0))
+            port = sock.getsockname()[1]
+        cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}',
+               '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        os.execv(sys.executable, cmd)
+
+
+def dry_run(args):
+    """BENCH_DRY=1: the launch/rendezvous/reporting skeleton without any GPU work, so that the N > 1 path (respawn,
+    process group, barrier, max-over-ranks, one JSON line from rank 0) is testable on a CPU box with gloo."""
+    from boardlaw_amd import parallel
+    rank, world, _ = parallel.env_rank()
+    parallel.init(os.environ.get('BENCH_BACKEND', 'gloo'))
+    parallel.barrier()
+    t0 = time.perf_counter()
+    time.sleep(0.01 * (rank + 1))
+    parallel.barrier()
+    elapsed = parallel.max_over_ranks(time.perf_counter() - t0, device='cpu')
+    if rank == 0:
+        print(json.dumps({'metric': 'mcts_sims_per_sec', 'value': 0.0, 'unit': 'sims/s', 'n_gpus': world, 'steps': args.steps,
+                          'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed, 'dry_run': True}))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
 def main():
     global BOARD, NODES, WIDTH, DEPTH
     ap = argparse.ArgumentParser()
@@ -117,12 +154,16 @@ def main():
     ap.add_argument('--torch-gemms', action='store_true', help='keep the Linears as torch (hipBLASLt) GEMMs instead of the fused MFMA kernel')
     ap.add_argument('--eager', action='store_true', help='launch kernel by kernel instead of replaying a HIP graph per move')
     args = ap.parse_args()
+    respawn_per_gpu(args)
     BOARD, NODES, WIDTH, DEPTH = args.boardsize, args.nodes, args.width, args.depth
     default_shape = (BOARD, NODES, WIDTH, DEPTH) == (9, 64, 512, 4)
+    if os.environ.get('BENCH_DRY') == '1':
+        return dry_run(args)
 
     assert torch.cuda.is_available(), 'bench.py needs an MI355X; there is no CPU path'
     from boardlaw_amd import parallel
     rank, world, local = parallel.env_rank()
+    assert world == args.gpus, (world, args.gpus)
     # BENCH_FORCE_DEVICE / BENCH_BACKEND exist only to smoke-test the N>1 code path on a 1-GPU box (two ranks sharing
     # device 0 over gloo); the driver's multi-GPU runs use one device per rank and RCCL.
     local = int(os.environ.get('BENCH_FORCE_DEVICE', local))

@@ -753,7 +753,7 @@ __global__ void __launch_bounds__(256) hex_observe_kernel(const uint8_t* board, 
 struct Search {
     uint16_t* logits; uint16_t* v; uint16_t* w; int16_t* n; int16_t* children; int16_t* parents; int16_t* relation;
     uint16_t* rewards; uint8_t* terminal; uint8_t* boards; int32_t* seats; const uint16_t* c_puct; uint32_t* qrange;
-    const float* exp_table; int B, T, S; int obs_f16; int16_t* path;
+    const float* exp_table; int B, T, S; int obs_f16; int16_t* path; const int32_t* order; int prio_thresh;
 };
 
 template <int G, int K, bool COUNT>
@@ -763,10 +763,14 @@ __global__ void __launch_bounds__(BL_WAVE) sim_expand_kernel(Search s, int sim, 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int S = s.S, A = S * S, T = s.T;
     const int grp = threadIdx.x / G, gl = threadIdx.x % G;
-    const int b = blockIdx.x * (BL_WAVE / G) + grp;
-    const bool act = b < s.B;
+    const int slot = blockIdx.x * (BL_WAVE / G) + grp;
+    const bool act = slot < s.B;
+    // launch slot -> env: with an `order` the host decides which envs are dispatched first (oldest wave on a SIMD wins
+    // the issue arbitration); results do not depend on it
+    const int b = (s.order && act) ? s.order[slot] : slot;
     const GroupLds L(smem + (size_t)grp * lds_bytes(A, true), A);
     uint8_t* cells = L.cells;
+    if (s.prio_thresh > 0 && s.path && act && s.path[(long)b * (T + 2)] >= s.prio_thresh) __builtin_amdgcn_s_setprio(3);
 
     Tree m;
     m.logits = s.logits; m.w = s.w; m.n = s.n; m.c_puct = s.c_puct; m.seats = s.seats; m.terminal = s.terminal;
@@ -1338,7 +1342,7 @@ static int search_check(const bl_search_t* s) {
 static Search to_search(const bl_search_t* s) {
     return Search{(uint16_t*)s->logits, (uint16_t*)s->v, (uint16_t*)s->w, s->n, s->children, s->parents, s->relation,
                   (uint16_t*)s->rewards, s->terminal, s->boards, s->seats, (const uint16_t*)s->c_puct, s->qrange,
-                  s->exp_table, s->B, s->T, s->boardsize, s->obs_f16, s->path};
+                  s->exp_table, s->B, s->T, s->boardsize, s->obs_f16, s->path, s->order, s->prio_thresh};
 }
 
 static int sim_expand_impl(const bl_search_t* s, int sim, const void* rands, int16_t* leaves, void* obs, uint8_t* valid,

@@ -119,6 +119,10 @@ typedef struct {
                             the first Linear anyway; exact, the planes are 0/1) */
     int16_t* path;       /* (B,T+2) i16 scratch or NULL: bl_sim_expand records each descent as [len, root, ..., leaf] so
                             that bl_sim_finish can back up without chasing parents[]; required by bl_sim_finish */
+    const int32_t* order; /* (B) i32 or NULL: launch slot -> env for bl_sim_expand (a permutation of 0..B-1).  Only the
+                            dispatch order changes (e.g. deepest trees first), never a result */
+    int prio_thresh;     /* > 0: bl_sim_expand raises the wave priority of envs whose previous descent (path[0]) was at
+                            least this long; 0: off */
 } bl_search_t;
 
 /* mcts/__init__.py:113-129 + hex/__init__.py:148-195 for simulation number `sim` (1..T-1):

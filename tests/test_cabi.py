@@ -38,7 +38,22 @@ def test_argument_validation_without_gpu():
     assert L.bl_hex_observe(one, one, one, 4, 33, None) == -2
     assert L.bl_mcts_descend(*([one] * 10), 1, 1, 2000, 1, one, one, None) == -2
     assert b'limits' in L.bl_strerror(-2)
-    assert ctypes.sizeof(_native.Search) == 14 * 8 + 4 * 4 + 8
+
+
+def test_search_struct_layout_matches_the_header(tmp_path):
+    """bl_search_t as gcc lays it out from include/boardlaw_amd.h == the ctypes mirror, field by field."""
+    import subprocess
+    from boardlaw_amd import _native
+    names = [f[0] for f in _native.Search._fields_]
+    src = tmp_path / 'layout.c'
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "boardlaw_amd.h"\nint main(void) {\n'
+                   + ''.join(f'printf("{n} %zu\\n", offsetof(bl_search_t, {n}));\n' for n in names)
+                   + 'printf("sizeof %zu\\n", sizeof(bl_search_t)); return 0; }\n')
+    exe = tmp_path / 'layout'
+    subprocess.check_call(['gcc', '-I', os.path.join(ROOT, 'include'), str(src), '-o', str(exe)])
+    got = dict(l.split() for l in subprocess.check_output([str(exe)]).decode().splitlines())
+    assert int(got.pop('sizeof')) == ctypes.sizeof(_native.Search)
+    assert {k: int(v) for k, v in got.items()} == {n: getattr(_native.Search, n).offset for n in names}
 
 
 def test_exp_table_is_host_libm(oracle):

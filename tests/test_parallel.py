@@ -4,8 +4,11 @@ import os
 import socket
 
 import numpy as np
+import pytest
 import torch
 import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _free_port():
@@ -69,3 +72,35 @@ def test_shard_properties():
             assert all(a.stop == b.start for a, b in zip(sl, sl[1:]))
             sizes = [s.stop - s.start for s in sl]
             assert max(sizes) - min(sizes) <= 1
+
+
+def _bench(args, env):
+    import json, subprocess, sys
+    e = {**os.environ, **env}
+    e.pop('WORLD_SIZE', None); e.pop('RANK', None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py')] + args, env=e, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, out.stdout          # ONE JSON line, from rank 0
+    return json.loads(lines[0])
+
+
+def test_bench_gpus_flag_spawns_one_rank_per_gpu():
+    """`python bench.py --gpus 2` without a launcher re-executes itself as 2 ranks (dry run: rendezvous, barrier,
+    max-over-ranks and the single JSON line, no GPU work); a launcher whose world size disagrees with --gpus is refused."""
+    import subprocess, sys
+    d = _bench(['--gpus', '2', '--steps', '1', '--warmup', '0'], {'BENCH_DRY': '1', 'BENCH_BACKEND': 'gloo'})
+    assert d['n_gpus'] == 2 and d['ms_per_step'] >= 20.      # rank 1 sleeps 20 ms: the MAX over ranks is reported
+    assert _bench([], {'BENCH_DRY': '1'})['n_gpus'] == 1
+    bad = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2'], env={**os.environ, 'WORLD_SIZE': '3', 'BENCH_DRY': '1'},
+                         capture_output=True, text=True)
+    assert bad.returncode != 0 and 'WORLD_SIZE=3' in bad.stderr
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_on_one_gpu():
+    """The real bench with --gpus 2: two ranks sharing device 0 over gloo (the driver's runs use one device per rank and RCCL)."""
+    d = _bench(['--gpus', '2', '--steps', '2', '--warmup', '1', '--envs', '256', '--no-cpu-baseline'],
+               {'BENCH_BACKEND': 'gloo', 'BENCH_FORCE_DEVICE': '0'})
+    assert d['n_gpus'] == 2 and d['config']['parallelism'] == 'replicas x2' and d['value'] > 0
+    assert d['scaling'] == 'weak'
