@@ -18,7 +18,8 @@ class Search(ctypes.Structure):
     """bl_search_t"""
     _fields_ = [(k, _vp) for k in ('logits', 'v', 'w', 'n', 'children', 'parents', 'relation', 'rewards', 'terminal',
                                    'boards', 'seats', 'c_puct', 'qrange', 'exp_table')] + \
-               [('B', _i), ('T', _i), ('boardsize', _i), ('obs_f16', _i), ('path', _vp), ('order', _vp), ('prio_thresh', _i)]
+               [('B', _i), ('T', _i), ('boardsize', _i), ('obs_f16', _i), ('path', _vp), ('order', _vp), ('prio_thresh', _i),
+                ('cpi', _vp), ('cca', _vp), ('nk', _vp)]
 
 
 SYMBOLS = {
@@ -45,6 +46,9 @@ SYMBOLS = {
     'bl_rezero_relu_f32': (_i, [_vp] * 5 + [ctypes.c_long, _vp]),
     'bl_sim_plant_root': (_i, [ctypes.POINTER(Search)] + [_vp] * 5 + [ctypes.c_float, _vp]),
     'bl_sim_init': (_i, [ctypes.POINTER(Search), _vp, _vp, _vp]),
+    'bl_sim_compact': (_i, [ctypes.POINTER(Search), _vp, _vp]),
+    'bl_selftest': (_i, [_vp]),
+    'bl_fold_variant': (_i, []),
 }
 
 _lib = None
@@ -67,6 +71,11 @@ def lib():
             f = getattr(L, name)
             f.restype, f.argtypes = res, args
         _lib = L
+        if torch.cuda.is_available() and not torch.cuda.is_current_stream_capturing():
+            # verifies the one-wait-state DPP fold on this device; the ISA-padded variant stays in use otherwise
+            rc = L.bl_selftest(torch.cuda.current_stream().cuda_stream)
+            if rc < 0:
+                raise NativeError(f'libboardlaw_amd: device self-test failed ({L.bl_strerror(rc).decode()})')
     return _lib
 
 

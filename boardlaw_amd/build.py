@@ -7,8 +7,8 @@ import subprocess
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
-SOURCES = [os.path.join(HERE, 'csrc', 'bl_kernels.hip'), os.path.join(HERE, 'csrc', 'bl_mlp.hip')]
-HEADERS = [os.path.join(ROOT, 'include', 'boardlaw_amd.h')]
+SOURCES = [os.path.join(HERE, 'csrc', f) for f in ('bl_kernels.hip', 'bl_expand.hip', 'bl_mlp.hip')]
+HEADERS = [os.path.join(ROOT, 'include', 'boardlaw_amd.h'), os.path.join(HERE, 'csrc', 'bl_device.h')]
 LIB = os.path.join(HERE, 'libboardlaw_amd.so')
 
 # -ffp-contract=off: the search kernels must round like the reference's CPU path (no FMA); see DESIGN.md.

@@ -1,0 +1,180 @@
+// bl_device.h -- device helpers shared by the translation units of libboardlaw_amd.so (bl_kernels.hip, bl_expand.hip,
+// bl_mlp.hip): binary16 conversions, the order-preserving float<->u32 map of the q range, wave-wide DPP reductions,
+// the search view `Search`, the Hex step on a board held in LDS, and the writer of compacted policy rows.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <math.h>
+
+#pragma clang fp contract(off)
+
+#define BL_QSLOTS 64          // qrange state: 64 slots x {~enc(min), enc(max)} ...
+#define BL_QSTRIDE 64         // ... one slot per 256 B (64 words): same-line atomics serialise in L2 (~12 ns each)
+#define BL_QWORDS (BL_QSLOTS * BL_QSTRIDE)
+#define BL_WAVE 64
+
+namespace bl {
+
+typedef _Float16 f16_t;
+__device__ __forceinline__ float h2f(uint16_t b) { return (float)__builtin_bit_cast(f16_t, b); }
+__device__ __forceinline__ uint16_t f2h(float f) { return __builtin_bit_cast(uint16_t, (f16_t)f); }
+
+// order-preserving float <-> u32
+__host__ __device__ __forceinline__ uint32_t enc(float f) {
+    uint32_t b = __builtin_bit_cast(uint32_t, f);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__host__ __device__ __forceinline__ float dec(uint32_t u) {
+    uint32_t b = (u & 0x80000000u) ? (u & 0x7fffffffu) : ~u;
+    return __builtin_bit_cast(float, b);
+}
+
+template <int G> __device__ __forceinline__ int gsum(int x) {
+#pragma unroll
+    for (int m = G / 2; m > 0; m >>= 1) x += __shfl_xor(x, m, G);
+    return x;
+}
+template <int G> __device__ __forceinline__ float gmaxf(float x) {
+#pragma unroll
+    for (int m = G / 2; m > 0; m >>= 1) x = fmaxf(x, __shfl_xor(x, m, G));
+    return x;
+}
+template <int G> __device__ __forceinline__ uint32_t gmaxu(uint32_t x) {
+#pragma unroll
+    for (int m = G / 2; m > 0; m >>= 1) { uint32_t y = __shfl_xor((int)x, m, G); x = x > y ? x : y; }
+    return x;
+}
+
+// Reduce the 64 qrange slots: every lane of the wave returns {lo, hi}.  transition_q, cuda.cu:101-105.
+__device__ __forceinline__ void load_qrange(const uint32_t* qr, float& lo, float& hi) {
+    const int lane = threadIdx.x & 63;
+    uint32_t a = qr[BL_QSTRIDE * lane], b = qr[BL_QSTRIDE * lane + 1];
+    a = gmaxu<64>(a); b = gmaxu<64>(b);
+    lo = dec(~a); hi = dec(b);
+}
+
+__host__ __device__ __forceinline__ int al16(int x) { return (x + 15) & ~15; }
+
+template <int CTRL, int RM>
+__device__ __forceinline__ int dpp_i(int old, int v) { return __builtin_amdgcn_update_dpp(old, v, CTRL, RM, 0xf, false); }
+template <int CTRL, int RM>
+__device__ __forceinline__ float dpp_f(float old, float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, v), CTRL, RM, 0xf, false));
+}
+__device__ __forceinline__ int wave_sum_i32(int v) {     // integer: any order is exact
+    v += dpp_i<0x111, 0xf>(0, v); v += dpp_i<0x112, 0xf>(0, v); v += dpp_i<0x114, 0xf>(0, v); v += dpp_i<0x118, 0xf>(0, v);
+    v += dpp_i<0x142, 0xa>(0, v); v += dpp_i<0x143, 0xc>(0, v);
+    return __builtin_amdgcn_readlane(v, 63);
+}
+__device__ __forceinline__ float wave_max_f32(float v) {   // max: any order is exact
+    v = fmaxf(v, dpp_f<0x111, 0xf>(v, v)); v = fmaxf(v, dpp_f<0x112, 0xf>(v, v)); v = fmaxf(v, dpp_f<0x114, 0xf>(v, v));
+    v = fmaxf(v, dpp_f<0x118, 0xf>(v, v)); v = fmaxf(v, dpp_f<0x142, 0xa>(v, v)); v = fmaxf(v, dpp_f<0x143, 0xc>(v, v));
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
+    v = max(v, (uint32_t)dpp_i<0x111, 0xf>(0, (int)v)); v = max(v, (uint32_t)dpp_i<0x112, 0xf>(0, (int)v));
+    v = max(v, (uint32_t)dpp_i<0x114, 0xf>(0, (int)v)); v = max(v, (uint32_t)dpp_i<0x118, 0xf>(0, (int)v));
+    v = max(v, (uint32_t)dpp_i<0x142, 0xa>(0, (int)v)); v = max(v, (uint32_t)dpp_i<0x143, 0xc>(0, (int)v));
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+__device__ __forceinline__ float readlane_f(float v, int lane) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Hex.  Cell codes and rules: boardlaw/hex/cpp/cuda.cu:8-16,76-137; flood cuda.cu:18-74.
+// ------------------------------------------------------------------------------------------------------------------
+enum { EMPTY = 0, BLACK, WHITE, TOP, BOT, LEFT, RIGHT, MARK = 0xff };
+
+// One group steps one board held in LDS `cells` (A bytes).  Returns the winner's sign in `win` (0 none, +1 black
+// wins => rewards (+1,-1), -1 white wins => (-1,+1)).  Group-uniform control flow; `go` false groups idle.
+template <int G>
+__device__ __forceinline__ int hex_step_group(uint8_t* cells, int S, int seat, int action, bool go, int gl) {
+    const int A = S * S;
+    const float invS = 1.0f / (float)S;
+    int label = 0, win = 0, start = 0;
+    uint8_t plain = 0;
+    if (go && gl == 0) {
+        const int qd = (int)(((float)action + 0.5f) * invS), rm = action - qd * S;
+        const int row = seat == 0 ? qd : rm, col = seat == 0 ? rm : qd;   // white plays transposed, cuda.cu:88-91
+        unsigned adj = 0;
+        const int dr[6] = {-1, -1, 0, 0, +1, +1}, dc[6] = {0, +1, -1, +1, -1, 0};
+#pragma unroll
+        for (int k = 0; k < 6; k++) {
+            const int r = row + dr[k], c = col + dc[k];
+            int code;
+            if (r < 0) code = TOP; else if (r >= S) code = BOT; else if (c < 0) code = LEFT; else if (c >= S) code = RIGHT;
+            else code = cells[r * S + c];
+            adj |= 1u << code;
+        }
+        const bool aT = adj & (1u << TOP), aB = adj & (1u << BOT), aL = adj & (1u << LEFT), aR = adj & (1u << RIGHT);
+        if (seat) { if (aL && aR) win = -1; label = aL ? LEFT : (aR ? RIGHT : WHITE); plain = WHITE; }
+        else      { if (aT && aB) win = +1; label = aT ? TOP : (aB ? BOT : BLACK); plain = BLACK; }
+        start = row * S + col;
+        // the reference writes the plain colour then floods from it; a flood relabels the start cell too
+        cells[start] = (label >= TOP) ? (uint8_t)MARK : plain;
+    }
+    label = __shfl(label, 0, G); win = __shfl(win, 0, G);
+    plain = (uint8_t)__shfl((int)plain, 0, G);
+    const bool flooding = go && label >= TOP;
+    __syncthreads();
+    // Relabel the 6-connected component of `plain` cells containing the start cell (== the BFS of cuda.cu:18-74):
+    // sweep until no plain cell touches a MARKed one.
+    while (true) {
+        bool changed = false;
+        if (flooding) {
+            for (int a = gl; a < A; a += G) {
+                if (cells[a] != plain) continue;
+                const int r = (int)(((float)a + 0.5f) * invS), c = a - r * S;
+                bool hit = false;
+                if (r > 0) { hit |= cells[a - S] == MARK; if (c < S - 1) hit |= cells[a - S + 1] == MARK; }
+                if (c > 0) hit |= cells[a - 1] == MARK;
+                if (c < S - 1) hit |= cells[a + 1] == MARK;
+                if (r < S - 1) { hit |= cells[a + S] == MARK; if (c > 0) hit |= cells[a + S - 1] == MARK; }
+                if (hit) { cells[a] = MARK; changed = true; }
+            }
+        }
+        __syncthreads();
+        if (!__any(changed)) break;
+    }
+    if (flooding) for (int a = gl; a < A; a += G) if (cells[a] == MARK) cells[a] = (uint8_t)label;
+    __syncthreads();
+    return win;
+}
+
+__device__ __forceinline__ int color_of(int c) { return (c == BLACK || c == TOP || c == BOT) ? 0 : ((c == WHITE || c == LEFT || c == RIGHT) ? 1 : 2); }
+
+struct Search {
+    uint16_t* logits; uint16_t* v; uint16_t* w; int16_t* n; int16_t* children; int16_t* parents; int16_t* relation;
+    uint16_t* rewards; uint8_t* terminal; uint8_t* boards; int32_t* seats; const uint16_t* c_puct; uint32_t* qrange;
+    const float* exp_table; int B, T, S; int obs_f16; int16_t* path; const int32_t* order; int prio_thresh;
+    float* cpi; uint32_t* cca; int16_t* nk;      // compacted policy rows, see compact_store()
+};
+
+// ------------------------------------------------------------------------------------------------------------------
+// Compacted policy rows.  A descent level needs, per action with pi = expf(logit) != 0, {pi, the action, its child}.
+// Actions with pi == 0 (illegal moves carry logit -inf) contribute s = +0 and g = -0 to the Newton sums -- x + (+-0) == x
+// for every partial sum, so they change no rounding -- have probability 0, are never drawn and never get a child
+// (cuda.cu:23-25,157-176).  Whoever stores a node's logits therefore also stores the row squeezed to the kept actions,
+// in ascending action order:
+//     cpi[b,t,j] f32 = exp_table[logit bits]          cca[b,t,j] u32 = child << 16 | action   (child = 0xffff: none yet)
+//     nk[b,t]    i16 = number of kept actions
+// bl_sim_expand reads these instead of logits[b,t,:] / children[b,t,:] (which stay maintained: they are the API).
+// One wave per env; every lane passes its action's f16 logit bits (`a` ascending with the call order, `a < A` lanes
+// only) and gets the running count back.  The exp-table gather is the only dependent load.
+// ------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int compact_store(const Search& s, long node, int A, int a, bool in, uint16_t logit_bits, int count) {
+    const int lane = threadIdx.x & 63;
+    float pi = 0.f;
+    if (in) pi = s.exp_table[logit_bits];
+    const bool keep = in && pi != 0.f;
+    const unsigned long long mk = __ballot(keep);
+    if (keep) {
+        const int j = count + __builtin_popcountll(mk & ((1ull << lane) - 1ull));
+        s.cpi[node * A + j] = pi;
+        s.cca[node * A + j] = 0xffff0000u | (uint32_t)a;
+    }
+    return count + __builtin_popcountll(mk);
+}
+
+}  // namespace bl

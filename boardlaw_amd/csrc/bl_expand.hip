@@ -1,0 +1,432 @@
+// bl_expand.hip -- bl_sim_expand on the compacted policy rows: descend (mcts/cpp/cuda.cu:138-182) + tree expansion
+// (mcts/__init__.py:117-129) + Hex step/observe (hex/cpp/cuda.cu:76-195) for one simulation, one wave per env.
+//
+// What bounds this kernel is not HBM and not VALU throughput but the LATENCY of one wave's dependent chain: the launch
+// ends with its deepest env (25 levels at 9x9/64 sims against 5 on average), which runs alone on its SIMD for most of
+// its life.  Everything here is arranged to shorten that chain, bit for bit the same arithmetic as the reference:
+//
+//  * per-node statistics live in registers.  Lane t loads {w[b,t,:], n[b,t], nk, seat, terminal, rand[b,t]} of node
+//    slot t once, at the start (T <= 256: 1..4 registers each); a level looks its children up with ds_bpermute and the
+//    next node's seat/terminal/uniform with v_readlane -- no second memory round trip per level.
+//  * compacted rows (bl_device.h: compact_store): a level loads pi and (child, action) of the kept actions only -- no
+//    exp-table gather, no in-kernel compaction, half the row bytes on a mid-game board.
+//  * ONE dependent DPP chain per level.  The Newton sums S = sum s_a and g = sum g_a must be folded in ascending action
+//    order (float addition is not associative and the drawn action depends on every rounding).  Element e of a block
+//    of 32 kept actions is evaluated by lane e (s term: top/(alpha-q)) and by lane 32+e (g term: -top/(alpha-q)^2) --
+//    one IEEE division per lane instead of two -- and `v_add_f32_dpp row_shr:1` advances both chains, in all four
+//    16-lane rows, with one instruction per step; rows hand over with row_bcast:15, blocks with row_bcast:15 (lane 31
+//    -> 32) and wave_ror:1 (lane 63 -> 0), the S/g halves swapping sides from block to block so that both carries are
+//    "next row" moves.  Each lane's last update reads a neighbour that is already final, so after j steps lanes 0..j of
+//    a row hold the reference's running totals exactly; the totals stay in registers for the draw (cuda.cu:157-176).
+//  * wait states: the ISA asks for 2 between a VALU write and a DPP read of the same VGPR (no interlock).  The SAFE
+//    variant pads every step with `s_nop 1`; the FAST one with `s_nop 0`, which tools/micro/fold_variants.hip measures
+//    as sufficient on gfx950 (a padded step then takes as long as the hardware-interlocked dependent v_add: 8.8 vs 9.2
+//    cycles).  FAST is used only after bl_selftest() has verified it on the device at hand (bl_kernels.hip).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <math.h>
+#include "../../include/boardlaw_amd.h"
+#include "bl_device.h"
+
+#pragma clang fp contract(off)
+
+namespace bl {
+
+#define BLX_ROWSTEP "v_add_f32_dpp %0, %0, %1 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+#define BLX_STEP7(NOP) BLX_ROWSTEP NOP BLX_ROWSTEP NOP BLX_ROWSTEP NOP BLX_ROWSTEP NOP BLX_ROWSTEP NOP BLX_ROWSTEP NOP BLX_ROWSTEP NOP
+#define BLX_STEP8(NOP) BLX_STEP7(NOP) BLX_ROWSTEP NOP
+
+// 7 resp. 8 in-row steps of the chain, all four rows at once.  Steps beyond the ones a row needs recompute the same values,
+// so a half row of up to 8 elements takes fold7 and a longer one fold7 + fold8: at most three uniform branches per block.
+template <bool FAST>
+__device__ __forceinline__ void fold7(float& x, const float t) {
+    if constexpr (FAST) asm volatile("s_nop 0\n\t" BLX_STEP7("s_nop 0\n\t") : "+v"(x) : "v"(t));
+    else asm volatile("s_nop 1\n\t" BLX_STEP7("s_nop 1\n\t") : "+v"(x) : "v"(t));
+}
+template <bool FAST>
+__device__ __forceinline__ void fold8(float& x, const float t) {
+    if constexpr (FAST) asm volatile(BLX_STEP8("s_nop 0\n\t") : "+v"(x) : "v"(t));
+    else asm volatile(BLX_STEP8("s_nop 1\n\t") : "+v"(x) : "v"(t));
+}
+
+// One block of m <= 32 elements whose lanes 0 and 32 already hold their final values.
+template <bool FAST>
+__device__ __forceinline__ void fold_block(float& x, const float t, const int m);
+
+// rows 0 -> 1 and 2 -> 3 of one block: lane 16 <- x[15] + t[16], lane 48 <- x[47] + t[48]  (lanes 4, 8, 12 of those rows
+// receive values that later steps overwrite)
+template <bool FAST>
+__device__ __forceinline__ void fold_mid(float& x, const float t) {
+    if constexpr (FAST) asm volatile("s_nop 0\n\tv_add_f32_dpp %0, %0, %1 row_bcast:15 row_mask:0xa bank_mask:0x1\n\ts_nop 0\n\t" : "+v"(x) : "v"(t));
+    else asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %0, %1 row_bcast:15 row_mask:0xa bank_mask:0x1\n\ts_nop 1\n\t" : "+v"(x) : "v"(t));
+}
+
+// block r-1 -> block r: lane 32 <- xprev[31] + t[32] (row_bcast:15 into row 2), lane 0 <- xprev[63] + t[0] (wave_ror:1)
+template <bool FAST>
+__device__ __forceinline__ void fold_carry(float& x, const float xprev, const float t) {
+    if constexpr (FAST)
+        asm volatile("s_nop 0\n\tv_add_f32_dpp %0, %1, %2 row_bcast:15 row_mask:0x4 bank_mask:0x1\n\t"
+                     "v_add_f32_dpp %0, %1, %2 wave_ror:1 row_mask:0x1 bank_mask:0x1\n\ts_nop 0\n\t" : "+v"(x) : "v"(xprev), "v"(t));
+    else
+        asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %1, %2 row_bcast:15 row_mask:0x4 bank_mask:0x1\n\t"
+                     "v_add_f32_dpp %0, %1, %2 wave_ror:1 row_mask:0x1 bank_mask:0x1\n\ts_nop 1\n\t" : "+v"(x) : "v"(xprev), "v"(t));
+}
+
+template <bool FAST>
+__device__ __forceinline__ void fold_block(float& x, const float t, const int m) {
+    fold7<FAST>(x, t);
+    if (m > 8) fold8<FAST>(x, t);
+    if (m > 16) {
+        fold_mid<FAST>(x, t);
+        fold7<FAST>(x, t);
+        if (m > 24) fold8<FAST>(x, t);
+    }
+}
+
+__device__ __forceinline__ int bperm_i(int src_lane, int v) { return __builtin_amdgcn_ds_bpermute(src_lane << 2, v); }
+
+// ------------------------------------------------------------------------------------------------------------------
+// RMAX: blocks of 32 kept actions a node can have (ceil(A / 32));  KT: registers of node slots (ceil(T / 64)).
+// ------------------------------------------------------------------------------------------------------------------
+template <int RMAX, int KT, bool FAST, bool COUNT>
+__global__ void __launch_bounds__(BL_WAVE) sim_expand2_kernel(Search s, int sim, const uint16_t* rands, int16_t* leaves_out,
+                                                              void* obs_out, uint8_t* valid_out, int32_t* leaf_seats_out,
+                                                              unsigned long long* counters) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    uint8_t* cells = (uint8_t*)smem;
+    const int S = s.S, A = S * S, T = s.T;
+    const int lane = threadIdx.x;
+    const int slot = blockIdx.x;
+    const int b = s.order ? s.order[slot] : slot;
+    const long envbase = (long)b * T;
+    const bool lowhalf = lane < 32;
+    const int el = lane & 31;
+    int16_t* path = s.path ? s.path + (long)b * (T + 2) : nullptr;
+    if (s.prio_thresh > 0 && path) {
+        // s_setprio ignores EXEC: the condition has to be an SGPR compare (readfirstlane), not a divergent branch
+        if (__builtin_amdgcn_readfirstlane((int)path[0]) >= s.prio_thresh) __builtin_amdgcn_s_setprio(3);
+    }
+    long long tk0 = 0, tk1 = 0, tsetup = 0, tterms = 0, tfold = 0, tupd = 0;
+    if (COUNT) tk0 = clock64();
+
+    // ---- the env's node slots, lane t <-> slot kt*64 + t
+    uint32_t wp[KT];      // w[b,t,0] | w[b,t,1] << 16
+    int nn[KT];           // n[b,t]
+    int info[KT];         // nk | seat << 16 | terminal << 17
+    int rd[KT];           // rand[b,t] (f16 bits)
+#pragma unroll
+    for (int kt = 0; kt < KT; kt++) {
+        const int tt = kt * 64 + lane;
+        wp[kt] = 0; nn[kt] = 0; info[kt] = 0; rd[kt] = 0;
+        if (tt < T) {
+            wp[kt] = *(const uint32_t*)(s.w + (envbase + tt) * 2);
+            nn[kt] = s.n[envbase + tt];
+            info[kt] = (int)(uint16_t)s.nk[envbase + tt] | ((s.seats[envbase + tt] & 1) << 16) | ((s.terminal[envbase + tt] ? 1 : 0) << 17);
+            rd[kt] = rands[envbase + tt];
+        }
+    }
+    float lo, hi;
+    load_qrange(s.qrange + (long)BL_QWORDS * sim, lo, hi);
+    const float rden = hi - lo + 1.e-4f;
+    const float cpuct = h2f(s.c_puct[b]);
+
+    auto slot_info = [&](int t) {
+        int v = 0;
+#pragma unroll
+        for (int kt = 0; kt < KT; kt++) if ((t >> 6) == kt) v = __builtin_amdgcn_readlane(info[kt], t & 63);
+        return v;
+    };
+    auto slot_rand = [&](int t) {
+        int v = 0;
+#pragma unroll
+        for (int kt = 0; kt < KT; kt++) if ((t >> 6) == kt) v = __builtin_amdgcn_readlane(rd[kt], t & 63);
+        return h2f((uint16_t)v);
+    };
+
+    // ---- descend_kernel's loop, cuda.cu:138-182
+    int t = 0, parent = 0, action = -1, nlev = 0, sel_e = 0;
+    int tinfo = __builtin_amdgcn_readfirstlane(slot_info(0));
+    bool live = true;
+    for (int depth = 0; depth < T; depth++) {
+        if (!live || t == -1 || ((tinfo >> 17) & 1)) break;
+        if (path && lane == 0) path[1 + depth] = (int16_t)t;
+        nlev = depth + 1;
+        long long tp0 = 0;
+        if (COUNT) tp0 = clock64();
+        const int nk = __builtin_amdgcn_readfirstlane(tinfo & 0xffff), seat = __builtin_amdgcn_readfirstlane((tinfo >> 16) & 1);
+        const int R = (nk + 31) >> 5;
+        const float rnd = slot_rand(t);
+        const long row = (envbase + t) * A;
+
+        // policy(), cuda.cu:70-99, on the node's kept actions: element e = 32 r + (lane & 31), in both halves of the wave
+        float top[RMAX], q[RMAX], term[RMAX], x[RMAX];
+        uint32_t cc[RMAX];
+        bool in[RMAX];
+#pragma unroll
+        for (int r = 0; r < RMAX; r++) {
+            const int e = 32 * r + el;
+            in[r] = (r < R) && (e < nk);
+            top[r] = 0.f; cc[r] = 0xffff0000u; q[r] = 0.f; term[r] = 0.f; x[r] = 0.f;
+            if (in[r]) { top[r] = s.cpi[row + e]; cc[r] = s.cca[row + e]; }
+        }
+        int Nloc = 0, nch = 0;
+#pragma unroll
+        for (int r = 0; r < RMAX; r++) {
+            if (r < R) {                                                  // wave-uniform: the bpermutes run with every lane enabled
+                const int c = (int)(int16_t)(cc[r] >> 16);
+                const bool ex = c >= 0;
+                const int src = ex ? c : 0;
+                uint32_t w2 = 0; int nv = 0;
+#pragma unroll
+                for (int kt = 0; kt < KT; kt++) {
+                    const uint32_t a_ = (uint32_t)bperm_i(src & 63, (int)wp[kt]);
+                    const int b_ = bperm_i(src & 63, nn[kt]);
+                    if ((src >> 6) == kt) { w2 = a_; nv = b_; }
+                }
+                if (ex) {
+                    const float wv = h2f((uint16_t)(seat ? (w2 >> 16) : w2));
+                    const float q32 = wv / ((float)nv + 1.e-4f);
+                    q[r] = h2f(f2h((q32 - lo) / rden));                  // transition_q, cuda.cu:101-105
+                }
+                if (lowhalf && in[r]) { Nloc += ex ? nv : 1; nch += ex ? 1 : 0; }
+            }
+        }
+        const int N = wave_sum_i32(Nloc) + (A - nk);                      // dropped actions are unexpanded: +1 each
+        const float lam = (cpuct * (float)N) / (float)(unsigned)(N + A);
+        float alpha = (nk < A) ? 1.e-4f : 0.f;                            // a dropped action's q + max(lambda pi, 1e-4)
+#pragma unroll
+        for (int r = 0; r < RMAX; r++) {
+            top[r] = lam * top[r];
+            if (in[r]) alpha = fmaxf(alpha, q[r] + fmaxf(top[r], 1.e-4f));
+        }
+        alpha = wave_max_f32(alpha);
+        if (COUNT) tsetup += clock64() - tp0;
+
+        // newton_search, cuda.cu:35-68
+        float err = INFINITY;
+        int iters = 0;
+        const int last_e = nk - 1, rl = last_e >> 5;
+        const int laneS = (last_e & 31) + ((rl & 1) ? 32 : 0), laneG = (last_e & 31) + ((rl & 1) ? 0 : 32);
+        for (int it = 0; it < 101 && nk > 0; it++) {
+            long long ti0 = 0, ti1 = 0, ti2 = 0;
+            if (COUNT) ti0 = clock64();
+#pragma unroll
+            for (int r = 0; r < RMAX; r++) {
+                if (r < R) {
+                    const bool isS = lowhalf != ((r & 1) != 0);
+                    const float bot = alpha - q[r];
+                    const float num = isS ? top[r] : -top[r];
+                    const float den = isS ? bot : bot * bot;
+                    term[r] = in[r] ? num / den : 0.f;                    // prob(a), cuda.cu:23-25, resp. its derivative term
+                }
+            }
+            if (COUNT) { ti1 = clock64(); tterms += ti1 - ti0; }
+#pragma unroll
+            for (int r = 0; r < RMAX; r++) {
+                if (r < R) {
+                    x[r] = term[r];
+                    if (r == 0) { if (el == 0) x[0] = 0.f + x[0]; }          // the sums start from 0.f (cuda.cu:44): (+0) + (-0) = +0
+                    else fold_carry<FAST>(x[r], x[r - 1 < 0 ? 0 : r - 1], term[r]);
+                    fold_block<FAST>(x[r], term[r], nk - 32 * r);
+                }
+            }
+            float Ssum = 0.f, gsum_ = 0.f;
+#pragma unroll
+            for (int r = 0; r < RMAX; r++) if (r == rl) { Ssum = readlane_f(x[r], laneS); gsum_ = readlane_f(x[r], laneG); }
+            if (COUNT) { ti2 = clock64(); tfold += ti2 - ti1; }
+            if (it == 100) break;      // alpha moved after the 100th fold (cuda.cu:48-65): this pass only refreshed the terms
+            iters++;
+            const float ne = Ssum - 1.f;
+            if ((ne < 1e-3f) || (err == ne)) break;
+            alpha -= ne / gsum_; err = ne;
+            if (COUNT) tupd += clock64() - ti2;
+        }
+
+        // the draw, cuda.cu:157-176: first kept action (ascending) with prob > 0 and running total >= rand, else the last
+        // with prob > 0.  The S half of block r holds prob in term[r] and the running totals in x[r].
+        int sel_r = -1, sel_lane = 0, last_r = -1, last_lane = 0;
+#pragma unroll
+        for (int r = 0; r < RMAX; r++) {
+            if (r < R) {
+                const bool isS = lowhalf != ((r & 1) != 0);
+                const bool pos = in[r] && isS && term[r] > 0.f;
+                const unsigned long long hit = __ballot(pos && x[r] >= rnd), anyp = __ballot(pos);
+                if (sel_r < 0 && hit) { sel_r = r; sel_lane = __builtin_ctzll(hit); }
+                if (anyp) { last_r = r; last_lane = 63 - __builtin_clzll(anyp); }
+            }
+        }
+        if (sel_r < 0) { sel_r = last_r; sel_lane = last_lane; }
+        parent = t;
+        if (COUNT) {
+            const int nc = wave_sum_i32(nch);
+            if (lane == 0) {
+                unsigned long long* e = counters + 12 * (long)b;
+                e[0] += 1; e[1] += iters; if ((unsigned long long)iters > e[2]) e[2] = iters; e[3] += nc;
+            }
+        }
+        if (sel_r < 0) { action = -1; live = false; break; }     // no action with positive probability: the reference would index [-1]
+        uint32_t ccs = 0;
+#pragma unroll
+        for (int r = 0; r < RMAX; r++) if (r == sel_r) ccs = (uint32_t)__builtin_amdgcn_readlane((int)cc[r], sel_lane);
+        action = (int)(ccs & 0xffffu);
+        sel_e = 32 * sel_r + (sel_lane & 31);
+        t = __builtin_amdgcn_readfirstlane((int)(int16_t)(ccs >> 16));
+        if (t != -1) tinfo = __builtin_amdgcn_readfirstlane(slot_info(t));
+    }
+    if (action < 0) action = 0;
+    if (COUNT) tk1 = clock64();
+
+    // ---- leaves = children[envs, parents, actions]; leaves[leaves == -1] = sim   (mcts/__init__.py:117-122)
+    const int nxt = t;
+    const int leaf = (nxt == -1) ? sim : nxt;
+    if (lane == 0) {
+        s.children[(envbase + parent) * A + action] = (int16_t)leaf;
+        s.parents[envbase + leaf] = (int16_t)parent;
+        s.relation[envbase + leaf] = (int16_t)action;
+        if (nxt == -1 && nlev > 0) ((uint16_t*)(s.cca + (envbase + parent) * A + sel_e))[1] = (uint16_t)leaf;   // the compacted row's child field
+    }
+    const int seat = s.seats[envbase + parent];
+    const uint8_t* src = s.boards + (envbase + parent) * A;
+    for (int a = lane; a < A; a += 64) cells[a] = src[a];
+    __syncthreads();
+    const int win = hex_step_group<64>(cells, S, seat, action, true, lane);
+    // Hex.step tail, hex/__init__.py:183-190
+    const bool term = win != 0;
+    const int new_seat = term ? 0 : 1 - seat;
+    uint8_t* dst = s.boards + (envbase + leaf) * A;
+    const float invS = 1.0f / (float)S;
+    const bool flip = new_seat == 1;
+    for (int a = lane; a < A; a += 64) dst[a] = term ? (uint8_t)0 : cells[a];
+    for (int a = lane; a < A; a += 64) {
+        const int i = (int)(((float)a + 0.5f) * invS), j = a - i * S;
+        const int color = term ? 2 : color_of(cells[flip ? j * S + i : a]);
+        const int ch = color < 2 ? (flip ? 1 - color : color) : 2;
+        if (s.obs_f16) ((uint32_t*)obs_out)[(long)b * A + a] = ch == 0 ? 0x00003c00u : (ch == 1 ? 0x3c000000u : 0u);   // f16 1.0 = 0x3c00
+        else ((float2*)obs_out)[(long)b * A + a] = make_float2(ch == 0 ? 1.f : 0.f, ch == 1 ? 1.f : 0.f);
+        valid_out[(long)b * A + a] = color == 2;
+    }
+    if (lane == 0) {
+        s.seats[envbase + leaf] = new_seat;
+        s.terminal[envbase + leaf] = term;
+        s.rewards[(envbase + leaf) * 2 + 0] = f2h((float)win);
+        s.rewards[(envbase + leaf) * 2 + 1] = f2h((float)(-win));
+        leaves_out[b] = (int16_t)leaf;
+        leaf_seats_out[b] = new_seat;
+        if (path) {
+            path[1 + nlev] = (int16_t)leaf;
+            path[0] = (int16_t)(nlev + 1);
+        }
+    }
+    if (COUNT && lane == 0) {
+        unsigned long long* e = counters + 12 * (long)b;
+        const long long tk2 = clock64();
+        e[4] += tsetup; e[5] += tterms; e[6] += tfold; e[7] += tupd;
+        e[8] += tk1 - tk0; e[9] += tk2 - tk1;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Self-test of the FAST fold on the device at hand: random positive/negative terms through fold_carry / fold_rows /
+// fold_mid exactly as the kernel chains them, against a serial sum by lane 0 through LDS.  out[0] += mismatching totals.
+// ------------------------------------------------------------------------------------------------------------------
+template <bool FAST>
+__global__ void __launch_bounds__(BL_WAVE) fold_selftest_kernel(uint32_t seed, int nk, unsigned int* bad) {
+    __shared__ float ts[3][64];
+    const int lane = threadIdx.x, el = lane & 31;
+    const bool lowhalf = lane < 32;
+    uint32_t h = seed * 2654435761u + blockIdx.x * 40503u + 12345u;
+    float term[3], x[3];
+    const int R = (nk + 31) >> 5;
+    for (int r = 0; r < 3; r++) {
+        const int e = 32 * r + el;
+        const bool isS = lowhalf != ((r & 1) != 0);
+        uint32_t k = (h ^ (uint32_t)(e * 2 + (isS ? 0 : 1)) * 0x9E3779B1u); k ^= k >> 15; k *= 0x85EBCA6Bu; k ^= k >> 13;
+        const float mag = __builtin_bit_cast(float, 0x3a000000u + (k & 0x03ffffffu));       // ~[5e-4, 8) spread over 7 binades
+        term[r] = (e < nk && r < R) ? (isS ? mag : -mag) : 0.f;
+        ts[r][lane] = term[r];
+        x[r] = 0.f;
+    }
+    __syncthreads();
+    for (int r = 0; r < 3; r++) {
+        if (r < R) {
+            x[r] = term[r];
+            if (r == 0) { if (el == 0) x[0] = 0.f + x[0]; }
+            else fold_carry<FAST>(x[r], x[r - 1 < 0 ? 0 : r - 1], term[r]);
+            fold_block<FAST>(x[r], term[r], nk - 32 * r);
+        }
+    }
+    // serial reference, lane 0: S elements then g elements, every prefix
+    __shared__ float want[2][96];
+    if (lane == 0) {
+        float aS = 0.f, aG = 0.f;
+        for (int e = 0; e < nk; e++) {
+            const int r = e >> 5, i = e & 31;
+            const int lS = i + ((r & 1) ? 32 : 0), lG = i + ((r & 1) ? 0 : 32);
+            aS = aS + ts[r][lS]; aG = aG + ts[r][lG];
+            want[0][e] = aS; want[1][e] = aG;
+        }
+    }
+    __syncthreads();
+    unsigned wrong = 0;
+    for (int r = 0; r < 3; r++) {
+        const int e = 32 * r + el;
+        if (r < R && e < nk) {
+            const bool isS = lowhalf != ((r & 1) != 0);
+            if (__builtin_bit_cast(uint32_t, x[r]) != __builtin_bit_cast(uint32_t, want[isS ? 0 : 1][e])) wrong++;
+        }
+    }
+    if (wrong) atomicAdd(bad, wrong);
+}
+
+}  // namespace bl
+
+using namespace bl;
+
+// Launches the compact-row kernel; returns BL_ETOOBIG when the shape is outside its template set (the caller then uses
+// the general kernel of bl_kernels.hip).
+int bl_expand2_launch(const Search& ss, int sim, const void* rands, int16_t* leaves, void* obs, uint8_t* valid, int32_t* leaf_seats,
+                      unsigned long long* counters, int fast, hipStream_t stream) {
+    const int A = ss.S * ss.S, T = ss.T;
+    if (!ss.cpi || !ss.cca || !ss.nk || A > 384 || T > 256) return BL_ETOOBIG;
+    const int need = (A + 31) / 32;
+    const int rmax = need <= 1 ? 1 : need <= 2 ? 2 : need <= 3 ? 3 : need <= 6 ? 6 : 12;
+    const int kt = T <= 64 ? 1 : 4;
+    const size_t lds = (size_t)al16(A);
+    const dim3 grid(ss.B), block(64);
+#define BLX_LAUNCH(R_, K_, F_, C_) hipLaunchKernelGGL((sim_expand2_kernel<R_, K_, F_, C_>), grid, block, lds, stream, ss, sim, \
+                                                      (const uint16_t*)rands, leaves, obs, valid, leaf_seats, counters)
+#define BLX_MODE(R_, K_) { if (counters) BLX_LAUNCH(R_, K_, true, true); else if (fast) BLX_LAUNCH(R_, K_, true, false); else BLX_LAUNCH(R_, K_, false, false); }
+#define BLX_KT(R_) { if (kt == 1) BLX_MODE(R_, 1) else BLX_MODE(R_, 4) }
+    switch (rmax) {
+        case 1: BLX_KT(1) break;
+        case 2: BLX_KT(2) break;
+        case 3: BLX_KT(3) break;
+        case 6: BLX_KT(6) break;
+        default: BLX_KT(12) break;
+    }
+#undef BLX_KT
+#undef BLX_MODE
+#undef BLX_LAUNCH
+    return hipGetLastError() == hipSuccess ? BL_OK : BL_ELAUNCH;
+}
+
+// Runs the fold self-test (both variants) and returns the number of wrong prefix totals of the FAST one (0 = the FAST
+// fold is exact on this device), or a negative BL_E* code.  Synchronises the stream.
+int bl_fold_selftest(int use_fast, hipStream_t stream) {
+    unsigned int* bad = nullptr;
+    if (hipMalloc(&bad, sizeof(unsigned int)) != hipSuccess) return BL_ELAUNCH;
+    unsigned int h = 0;
+    if (hipMemcpyAsync(bad, &h, sizeof(h), hipMemcpyHostToDevice, stream) != hipSuccess) { hipFree(bad); return BL_ELAUNCH; }
+    for (int rep = 0; rep < 6; rep++) {
+        for (int nk : {1, 2, 15, 16, 17, 31, 32, 33, 47, 48, 49, 54, 63, 64, 65, 80, 81, 96}) {
+            // 4096 waves: four per SIMD, the contention the search kernel runs under
+            if (use_fast) hipLaunchKernelGGL((fold_selftest_kernel<true>), dim3(4096), dim3(64), 0, stream, (uint32_t)(rep * 131 + nk), nk, bad);
+            else hipLaunchKernelGGL((fold_selftest_kernel<false>), dim3(4096), dim3(64), 0, stream, (uint32_t)(rep * 131 + nk), nk, bad);
+        }
+    }
+    hipError_t e = hipMemcpyAsync(&h, bad, sizeof(h), hipMemcpyDeviceToHost, stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(stream);
+    hipFree(bad);
+    if (e != hipSuccess || hipGetLastError() != hipSuccess) return BL_ELAUNCH;
+    return (int)(h > 0x3fffffffu ? 0x3fffffffu : h);
+}

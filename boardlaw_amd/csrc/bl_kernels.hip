@@ -15,45 +15,12 @@
 #include <string.h>
 #include <stdlib.h>
 #include "../../include/boardlaw_amd.h"
+#include "bl_device.h"
 
 #pragma clang fp contract(off)
 
-#define BL_QSLOTS 64          // qrange state: 64 slots x {~enc(min), enc(max)} ...
-#define BL_QSTRIDE 64         // ... one slot per 256 B (64 words): same-line atomics serialise in L2 (~12 ns each)
-#define BL_QWORDS (BL_QSLOTS * BL_QSTRIDE)
-#define BL_WAVE 64
 
 namespace bl {
-
-typedef _Float16 f16_t;
-__device__ __forceinline__ float h2f(uint16_t b) { return (float)__builtin_bit_cast(f16_t, b); }
-__device__ __forceinline__ uint16_t f2h(float f) { return __builtin_bit_cast(uint16_t, (f16_t)f); }
-
-// order-preserving float <-> u32
-__host__ __device__ __forceinline__ uint32_t enc(float f) {
-    uint32_t b = __builtin_bit_cast(uint32_t, f);
-    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
-}
-__host__ __device__ __forceinline__ float dec(uint32_t u) {
-    uint32_t b = (u & 0x80000000u) ? (u & 0x7fffffffu) : ~u;
-    return __builtin_bit_cast(float, b);
-}
-
-template <int G> __device__ __forceinline__ int gsum(int x) {
-#pragma unroll
-    for (int m = G / 2; m > 0; m >>= 1) x += __shfl_xor(x, m, G);
-    return x;
-}
-template <int G> __device__ __forceinline__ float gmaxf(float x) {
-#pragma unroll
-    for (int m = G / 2; m > 0; m >>= 1) x = fmaxf(x, __shfl_xor(x, m, G));
-    return x;
-}
-template <int G> __device__ __forceinline__ uint32_t gmaxu(uint32_t x) {
-#pragma unroll
-    for (int m = G / 2; m > 0; m >>= 1) { uint32_t y = __shfl_xor((int)x, m, G); x = x > y ? x : y; }
-    return x;
-}
 
 // View of the reference's `struct MCTS` (boardlaw/mcts/cpp/common.h:25-33) plus what transition_q needs.
 struct Tree {
@@ -74,18 +41,10 @@ __device__ __forceinline__ int load_seat(const Tree& m, long i) {
     return m.seats_i32 ? ((const int32_t*)m.seats)[i] : (int)((const int16_t*)m.seats)[i];
 }
 
-// Reduce the 64 qrange slots: every lane of the wave returns {lo, hi}.  transition_q, cuda.cu:101-105.
-__device__ __forceinline__ void load_qrange(const uint32_t* qr, float& lo, float& hi) {
-    const int lane = threadIdx.x & 63;
-    uint32_t a = qr[BL_QSTRIDE * lane], b = qr[BL_QSTRIDE * lane + 1];
-    a = gmaxu<64>(a); b = gmaxu<64>(b);
-    lo = dec(~a); hi = dec(b);
-}
 
 // ------------------------------------------------------------------------------------------------------------------
 // Per-group LDS carve-up (bytes, every array 16-B aligned):  s[A] f32 | g[A] f32 | child[A] i16 | info[A] u8 | cells[A] u8
 // ------------------------------------------------------------------------------------------------------------------
-__host__ __device__ __forceinline__ int al16(int x) { return (x + 15) & ~15; }
 __host__ __device__ __forceinline__ int lds_bytes(int A, bool with_cells) { return 2 * al16(4 * A) + al16(2 * A) + al16(A) + (with_cells ? al16(A) : 0); }
 
 struct GroupLds {
@@ -262,31 +221,6 @@ __device__ __forceinline__ int policy_eval(const Tree& m, int b, int t, int seat
 // finish a 64-action register; the totals stay in registers, which is what the draw needs.  S and g chains interleave,
 // filling each other's DPP wait states.
 // ------------------------------------------------------------------------------------------------------------------
-template <int CTRL, int RM>
-__device__ __forceinline__ int dpp_i(int old, int v) { return __builtin_amdgcn_update_dpp(old, v, CTRL, RM, 0xf, false); }
-template <int CTRL, int RM>
-__device__ __forceinline__ float dpp_f(float old, float v) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, v), CTRL, RM, 0xf, false));
-}
-__device__ __forceinline__ int wave_sum_i32(int v) {     // integer: any order is exact
-    v += dpp_i<0x111, 0xf>(0, v); v += dpp_i<0x112, 0xf>(0, v); v += dpp_i<0x114, 0xf>(0, v); v += dpp_i<0x118, 0xf>(0, v);
-    v += dpp_i<0x142, 0xa>(0, v); v += dpp_i<0x143, 0xc>(0, v);
-    return __builtin_amdgcn_readlane(v, 63);
-}
-__device__ __forceinline__ float wave_max_f32(float v) {   // max: any order is exact
-    v = fmaxf(v, dpp_f<0x111, 0xf>(v, v)); v = fmaxf(v, dpp_f<0x112, 0xf>(v, v)); v = fmaxf(v, dpp_f<0x114, 0xf>(v, v));
-    v = fmaxf(v, dpp_f<0x118, 0xf>(v, v)); v = fmaxf(v, dpp_f<0x142, 0xa>(v, v)); v = fmaxf(v, dpp_f<0x143, 0xc>(v, v));
-    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
-}
-__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
-    v = max(v, (uint32_t)dpp_i<0x111, 0xf>(0, (int)v)); v = max(v, (uint32_t)dpp_i<0x112, 0xf>(0, (int)v));
-    v = max(v, (uint32_t)dpp_i<0x114, 0xf>(0, (int)v)); v = max(v, (uint32_t)dpp_i<0x118, 0xf>(0, (int)v));
-    v = max(v, (uint32_t)dpp_i<0x142, 0xa>(0, (int)v)); v = max(v, (uint32_t)dpp_i<0x143, 0xc>(0, (int)v));
-    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
-}
-__device__ __forceinline__ float readlane_f(float v, int lane) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
-}
 
 // One step of both chains.  The ISA asks for 2 wait states between a VALU write and a DPP read of the same VGPR; each
 // chain's next step is separated from its previous one by the other chain's instruction.  tools/micro/dpp_hazard.hip
@@ -625,63 +559,6 @@ __global__ void __launch_bounds__(256) backup_kernel(const uint16_t* v, uint16_t
 // ------------------------------------------------------------------------------------------------------------------
 // Hex.  Cell codes and rules: boardlaw/hex/cpp/cuda.cu:8-16,76-137; flood cuda.cu:18-74.
 // ------------------------------------------------------------------------------------------------------------------
-enum { EMPTY = 0, BLACK, WHITE, TOP, BOT, LEFT, RIGHT, MARK = 0xff };
-
-// One group steps one board held in LDS `cells` (A bytes).  Returns the winner's sign in `win` (0 none, +1 black
-// wins => rewards (+1,-1), -1 white wins => (-1,+1)).  Group-uniform control flow; `go` false groups idle.
-template <int G>
-__device__ __forceinline__ int hex_step_group(uint8_t* cells, int S, int seat, int action, bool go, int gl) {
-    const int A = S * S;
-    const float invS = 1.0f / (float)S;
-    int label = 0, win = 0, start = 0;
-    uint8_t plain = 0;
-    if (go && gl == 0) {
-        const int qd = (int)(((float)action + 0.5f) * invS), rm = action - qd * S;
-        const int row = seat == 0 ? qd : rm, col = seat == 0 ? rm : qd;   // white plays transposed, cuda.cu:88-91
-        unsigned adj = 0;
-        const int dr[6] = {-1, -1, 0, 0, +1, +1}, dc[6] = {0, +1, -1, +1, -1, 0};
-#pragma unroll
-        for (int k = 0; k < 6; k++) {
-            const int r = row + dr[k], c = col + dc[k];
-            int code;
-            if (r < 0) code = TOP; else if (r >= S) code = BOT; else if (c < 0) code = LEFT; else if (c >= S) code = RIGHT;
-            else code = cells[r * S + c];
-            adj |= 1u << code;
-        }
-        const bool aT = adj & (1u << TOP), aB = adj & (1u << BOT), aL = adj & (1u << LEFT), aR = adj & (1u << RIGHT);
-        if (seat) { if (aL && aR) win = -1; label = aL ? LEFT : (aR ? RIGHT : WHITE); plain = WHITE; }
-        else      { if (aT && aB) win = +1; label = aT ? TOP : (aB ? BOT : BLACK); plain = BLACK; }
-        start = row * S + col;
-        // the reference writes the plain colour then floods from it; a flood relabels the start cell too
-        cells[start] = (label >= TOP) ? (uint8_t)MARK : plain;
-    }
-    label = __shfl(label, 0, G); win = __shfl(win, 0, G);
-    plain = (uint8_t)__shfl((int)plain, 0, G);
-    const bool flooding = go && label >= TOP;
-    __syncthreads();
-    // Relabel the 6-connected component of `plain` cells containing the start cell (== the BFS of cuda.cu:18-74):
-    // sweep until no plain cell touches a MARKed one.
-    while (true) {
-        bool changed = false;
-        if (flooding) {
-            for (int a = gl; a < A; a += G) {
-                if (cells[a] != plain) continue;
-                const int r = (int)(((float)a + 0.5f) * invS), c = a - r * S;
-                bool hit = false;
-                if (r > 0) { hit |= cells[a - S] == MARK; if (c < S - 1) hit |= cells[a - S + 1] == MARK; }
-                if (c > 0) hit |= cells[a - 1] == MARK;
-                if (c < S - 1) hit |= cells[a + 1] == MARK;
-                if (r < S - 1) { hit |= cells[a + S] == MARK; if (c > 0) hit |= cells[a + S - 1] == MARK; }
-                if (hit) { cells[a] = MARK; changed = true; }
-            }
-        }
-        __syncthreads();
-        if (!__any(changed)) break;
-    }
-    if (flooding) for (int a = gl; a < A; a += G) if (cells[a] == MARK) cells[a] = (uint8_t)label;
-    __syncthreads();
-    return win;
-}
 
 template <int G>
 __global__ void __launch_bounds__(BL_WAVE) hex_step_kernel(uint8_t* board, const int32_t* seats, const int32_t* actions,
@@ -730,7 +607,6 @@ __global__ void __launch_bounds__(BL_WAVE) hex_world_step_kernel(const uint8_t* 
 }
 
 // observe, cuda.cu:154-195: mover sees itself in channel 0, playing top-to-bottom.
-__device__ __forceinline__ int color_of(int c) { return (c == BLACK || c == TOP || c == BOT) ? 0 : ((c == WHITE || c == LEFT || c == RIGHT) ? 1 : 2); }
 
 __global__ void __launch_bounds__(256) hex_observe_kernel(const uint8_t* board, const int32_t* seats, float2* obs, long cells, int S) {
     const int A = S * S;
@@ -750,11 +626,6 @@ __global__ void __launch_bounds__(256) hex_observe_kernel(const uint8_t* board, 
 // ------------------------------------------------------------------------------------------------------------------
 // Fused simulation step for Hex: mcts/__init__.py:113-129 + hex/__init__.py:148-195.
 // ------------------------------------------------------------------------------------------------------------------
-struct Search {
-    uint16_t* logits; uint16_t* v; uint16_t* w; int16_t* n; int16_t* children; int16_t* parents; int16_t* relation;
-    uint16_t* rewards; uint8_t* terminal; uint8_t* boards; int32_t* seats; const uint16_t* c_puct; uint32_t* qrange;
-    const float* exp_table; int B, T, S; int obs_f16; int16_t* path; const int32_t* order; int prio_thresh;
-};
 
 template <int G, int K, bool COUNT>
 __global__ void __launch_bounds__(BL_WAVE) sim_expand_kernel(Search s, int sim, const uint16_t* rands, int16_t* leaves_out,
@@ -891,6 +762,9 @@ __global__ void __launch_bounds__(BL_WAVE) sim_finish_kernel(Search s, int sim, 
     const int b = blockIdx.x, lane = threadIdx.x;
     const long envbase = (long)b * T;
     const int leaf = leaves[b];
+    uint16_t lb[16];
+#pragma unroll
+    for (int it = 0; it < 16; it++) lb[it] = 0;
     // ---- policy head
     if (lane < W) {
         float e[16];
@@ -914,8 +788,15 @@ __global__ void __launch_bounds__(BL_WAVE) sim_finish_kernel(Search s, int sim, 
 #pragma unroll
         for (int it = 0; it < 16; it++) {
             const int a = lane + it * W;
-            if (it < iters && a < A) dst[a] = f2h(e[it] - mx - lsum);
+            if (it < iters && a < A) { lb[it] = f2h(e[it] - mx - lsum); dst[a] = lb[it]; }
         }
+    }
+    if (s.cpi) {
+        int count = 0;
+#pragma unroll
+        for (int it = 0; it < 16; it++)
+            if (it < iters) count = compact_store(s, envbase + leaf, A, lane + it * W, lane < W && lane + it * W < A, lb[it], count);
+        if (lane == 0) s.nk[envbase + leaf] = (int16_t)count;
     }
     // ---- value head
     const uint16_t tv = f2h(tanhf(h2f(value_raw[b])));
@@ -963,6 +844,20 @@ __global__ void __launch_bounds__(BL_WAVE) sim_finish_kernel(Search s, int sim, 
         if (nmin > __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(p, nmin);
         if (vmax > __hip_atomic_load(p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(p + 1, vmax);
     }
+}
+
+// Compacted rows (bl_device.h: compact_store) for logits somebody else stored: node leaves[b] of every env, or node 0
+// when leaves is null (a planted root).  One wave per env.
+__global__ void __launch_bounds__(BL_WAVE) compact_rows_kernel(Search s, const int16_t* leaves) {
+    const int A = s.S * s.S, b = blockIdx.x, lane = threadIdx.x;
+    const long node = (long)b * s.T + (leaves ? (int)leaves[b] : 0);
+    int count = 0;
+    for (int a0 = 0; a0 < A; a0 += BL_WAVE) {
+        const int a = a0 + lane;
+        const bool in = a < A;
+        count = compact_store(s, node, A, a, in, in ? s.logits[node * A + a] : (uint16_t)0, count);
+    }
+    if (lane == 0) s.nk[node] = (int16_t)count;
 }
 
 // ReZero residual under fp16 autocast, fused (networks.py:17-18): x_out = x + alpha*y with torch's rounding points --
@@ -1024,6 +919,9 @@ __global__ void __launch_bounds__(BL_WAVE) sim_plant_root_kernel(Search s, const
     const int S = s.S, A = S * S, T = s.T;
     const int b = blockIdx.x, lane = threadIdx.x;
     const long envbase = (long)b * T;
+    uint16_t lb[16];
+#pragma unroll
+    for (int it = 0; it < 16; it++) lb[it] = 0;
     if (lane < W) {
         float e[16], d[16];
         float mx = -INFINITY, dsum = 0.f;
@@ -1055,9 +953,17 @@ __global__ void __launch_bounds__(BL_WAVE) sim_plant_root_kernel(Search s, const
             if (it < iters && a < A) {
                 float l = e[it] - mx - lsum;
                 if (draw) l = logf(expf(l) * keep + (d[it] / dsum) * eps);
-                dst[a] = f2h(l);
+                lb[it] = f2h(l);
+                dst[a] = lb[it];
             }
         }
+    }
+    if (s.cpi) {
+        int count = 0;
+#pragma unroll
+        for (int it = 0; it < 16; it++)
+            if (it < iters) count = compact_store(s, envbase, A, lane + it * W, lane < W && lane + it * W < A, lb[it], count);
+        if (lane == 0) s.nk[envbase] = (int16_t)count;
     }
     if (lane == 0) {
         const float tv = tanhf(value_raw[b]);
@@ -1091,6 +997,7 @@ __global__ void __launch_bounds__(256) sim_init_kernel(Search s, const uint8_t* 
     grid_fill(s.rewards, B * T * 2 * 2, 0);
     grid_fill(s.terminal, B * T, 0);
     grid_fill(s.qrange, (T + 1) * (size_t)BL_QWORDS * sizeof(uint32_t), 0);
+    if (s.nk) grid_fill(s.nk, B * T * 2, 0);
 }
 
 // worlds = stack([world] * T) (mcts/__init__.py:62): every node slot of env b starts as a copy of the root board and
@@ -1192,6 +1099,10 @@ static int check_launch() { return hipGetLastError() == hipSuccess ? BL_OK : BL_
         case 32: BL_DISPATCH_K(32, K, CALL) break;  case 64: BL_DISPATCH_K(64, K, CALL) break;        \
         default: return BL_ETOOBIG;                                                                  \
     }
+
+int bl_expand2_launch(const Search& ss, int sim, const void* rands, int16_t* leaves, void* obs, uint8_t* valid, int32_t* leaf_seats,
+                      unsigned long long* counters, int fast, hipStream_t stream);     // bl_expand.hip
+int bl_fold_selftest(int use_fast, hipStream_t stream);
 
 extern "C" {
 
@@ -1342,8 +1253,13 @@ static int search_check(const bl_search_t* s) {
 static Search to_search(const bl_search_t* s) {
     return Search{(uint16_t*)s->logits, (uint16_t*)s->v, (uint16_t*)s->w, s->n, s->children, s->parents, s->relation,
                   (uint16_t*)s->rewards, s->terminal, s->boards, s->seats, (const uint16_t*)s->c_puct, s->qrange,
-                  s->exp_table, s->B, s->T, s->boardsize, s->obs_f16, s->path, s->order, s->prio_thresh};
+                  s->exp_table, s->B, s->T, s->boardsize, s->obs_f16, s->path, s->order, s->prio_thresh,
+                  s->cpi, s->cca, s->nk};
 }
+
+// 1 once bl_selftest() has verified the one-wait-state fold on this device; BL_FOLD_SAFE=1 keeps the padded variant.
+static int g_fold_fast = 0;
+static int env_flag(const char* name) { const char* e = getenv(name); return e && atoi(e) != 0; }
 
 static int sim_expand_impl(const bl_search_t* s, int sim, const void* rands, int16_t* leaves, void* obs, uint8_t* valid,
                            int32_t* leaf_seats, unsigned long long* counters, bl_stream_t stream) {
@@ -1351,6 +1267,13 @@ static int sim_expand_impl(const bl_search_t* s, int sim, const void* rands, int
     if (rc) return rc;
     if (!rands || !leaves || !obs || !valid || !leaf_seats || sim < 1 || sim >= s->T) return BL_EINVAL;
     const int A = s->boardsize * s->boardsize;
+    static const int legacy = env_flag("BL_EXPAND_LEGACY");
+    if (!legacy && !forced_group() && s->cpi && s->cca && s->nk) {
+        // compacted rows + node statistics in registers + one DPP chain per level (bl_expand.hip); shapes outside its
+        // template set (A > 384 or T > 256) fall through to the general kernel
+        rc = bl_expand2_launch(to_search(s), sim, rands, leaves, obs, valid, leaf_seats, counters, g_fold_fast, (hipStream_t)stream);
+        if (rc != BL_ETOOBIG) return rc;
+    }
     const int G = pick_group(s->B, A), K = pick_k(A, G);
     const int per = lds_bytes(A, true);
     const int blocks = (s->B + 64 / G - 1) / (64 / G);
@@ -1388,8 +1311,28 @@ int bl_sim_backup(const bl_search_t* s, int sim, const int16_t* leaves, const vo
     const int blocks = (s->B + 3) / 4;
     hipLaunchKernelGGL(sim_backup_kernel, dim3(blocks), dim3(64), 0, (hipStream_t)stream, to_search(s), sim, leaves,
                        leaf_logits, logits_dtype, leaf_v, v_dtype);
+    if (s->cpi && s->cca && s->nk) hipLaunchKernelGGL(compact_rows_kernel, dim3(s->B), dim3(64), 0, (hipStream_t)stream, to_search(s), leaves);
     return check_launch();
 }
+
+int bl_sim_compact(const bl_search_t* s, const int16_t* leaves, bl_stream_t stream) {
+    int rc = search_check(s);
+    if (rc) return rc;
+    if (!s->cpi || !s->cca || !s->nk) return BL_EINVAL;
+    hipLaunchKernelGGL(compact_rows_kernel, dim3(s->B), dim3(64), 0, (hipStream_t)stream, to_search(s), leaves);
+    return check_launch();
+}
+
+int bl_selftest(bl_stream_t stream) {
+    const int wrong_safe = bl_fold_selftest(0, (hipStream_t)stream);
+    if (wrong_safe != 0) return wrong_safe < 0 ? wrong_safe : BL_ELAUNCH;      // the ISA-compliant fold must be exact
+    const int wrong_fast = bl_fold_selftest(1, (hipStream_t)stream);
+    if (wrong_fast < 0) return wrong_fast;
+    g_fold_fast = (wrong_fast == 0) && !env_flag("BL_FOLD_SAFE");
+    return wrong_fast;
+}
+
+int bl_fold_variant(void) { return g_fold_fast; }
 
 int bl_sim_finish(const bl_search_t* s, int sim, const int16_t* leaves, const void* policy_raw, const void* value_raw,
                   const uint8_t* valid, const int32_t* leaf_seats, bl_stream_t stream) {

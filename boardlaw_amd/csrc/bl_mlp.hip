@@ -47,6 +47,7 @@ struct FinArgs {
     uint16_t* logits; uint16_t* v; uint16_t* w; int16_t* n; const uint16_t* rewards; const uint8_t* terminal;
     const int16_t* path; uint32_t* qrange; const int16_t* leaves; const int32_t* leaf_seats; const uint8_t* valid;
     int T, A, Wsm, iters;
+    float* cpi; uint32_t* cca; int16_t* nk; const float* exp_table;      // compacted policy rows (bl_device.h), or cpi == null
 };
 #define BLM_QSLOTS 64
 #define BLM_QSTRIDE 64
@@ -392,20 +393,44 @@ __global__ void __launch_bounds__(WAVES * 64) mlp_kernel(Params p, FinArgs f) {
             for (int e = 0; e < EPW; e++) sum[e] = sum[e] + __shfl_xor(sum[e], off, 64);
         }
         uint16_t vb0[EPW], vb1[EPW];
+        uint16_t lb[EPW][2];
 #pragma unroll
         for (int e = 0; e < EPW; e++) {
             const int r = EPW * wave + e;
             const float lsum = logf(sum[e]);
+            lb[e][0] = f2h(ev[e][0] - mx[e] - lsum); lb[e][1] = f2h(ev[e][1] - mx[e] - lsum);
             if (fb[e] >= 0 && lane < Wsm) {
                 uint16_t* dst = f.logits + (envbase[e] + leaf[e]) * A;
-                if (lane < A) dst[lane] = f2h(ev[e][0] - mx[e] - lsum);
-                if (two && lane + Wsm < A) dst[lane + Wsm] = f2h(ev[e][1] - mx[e] - lsum);
+                if (lane < A) dst[lane] = lb[e][0];
+                if (two && lane + Wsm < A) dst[lane + Wsm] = lb[e][1];
             }
             // value head
             const uint16_t tv = f2h(tanhf(h2f(Out[r * p.NHpad + p.NH - 1])));
             const int mover = __builtin_amdgcn_readfirstlane(fmover[e]);
             vb0[e] = (mover == 0) ? tv : (uint16_t)(tv ^ 0x8000u); vb1[e] = (uint16_t)(vb0[e] ^ 0x8000u);
             if (fb[e] >= 0 && lane == 0) { f.v[(envbase[e] + leaf[e]) * 2] = vb0[e]; f.v[(envbase[e] + leaf[e]) * 2 + 1] = vb1[e]; }
+        }
+        // the leaf's compacted policy row for the descents to come (bl_device.h: compact_store, same order and values):
+        // the kept actions' pi = exp_table[logit bits] and (no child | action), squeezed in ascending action order
+        if (f.cpi) {
+            float pi[EPW][2];
+            bool in[EPW][2];
+#pragma unroll
+            for (int e = 0; e < EPW; e++) {
+                in[e][0] = fb[e] >= 0 && lane < Wsm && lane < A; in[e][1] = fb[e] >= 0 && two && lane < Wsm && lane + Wsm < A;
+                pi[e][0] = in[e][0] ? f.exp_table[lb[e][0]] : 0.f; pi[e][1] = in[e][1] ? f.exp_table[lb[e][1]] : 0.f;
+            }
+#pragma unroll
+            for (int e = 0; e < EPW; e++) {
+                const long rowbase = (envbase[e] + leaf[e]) * A;
+                const bool k0 = in[e][0] && pi[e][0] != 0.f, k1 = in[e][1] && pi[e][1] != 0.f;
+                const unsigned long long m0 = __ballot(k0), m1 = __ballot(k1);
+                const unsigned long long below = (1ull << lane) - 1ull;
+                const int c0 = __builtin_popcountll(m0);
+                if (k0) { const int j = __builtin_popcountll(m0 & below); f.cpi[rowbase + j] = pi[e][0]; f.cca[rowbase + j] = 0xffff0000u | (uint32_t)lane; }
+                if (k1) { const int j = c0 + __builtin_popcountll(m1 & below); f.cpi[rowbase + j] = pi[e][1]; f.cca[rowbase + j] = 0xffff0000u | (uint32_t)(lane + Wsm); }
+                if (fb[e] >= 0 && lane == 0) f.nk[envbase[e] + leaf[e]] = (int16_t)(c0 + __builtin_popcountll(m1));
+            }
         }
         // backup (cuda.cu:205-236), leaf -> root: node j's value is v_j = (terminal_j ? 0 : v_{j+1}) + r_j with v_len the
         // leaf evaluation.  Every lane applies that step to its right neighbour's current value at once; after k rounds
@@ -550,6 +575,7 @@ extern "C" int bl_sim_infer_finish(const bl_search_t* s, int sim, const int16_t*
     int np2 = 1; while (np2 < A) np2 *= 2;
     const int Wsm = np2 < 64 ? np2 : 64;
     FinArgs f{(uint16_t*)s->logits, (uint16_t*)s->v, (uint16_t*)s->w, s->n, (const uint16_t*)s->rewards, s->terminal, s->path,
-              s->qrange + (long)BLM_QSLOTS * BLM_QSTRIDE * (sim + 1), leaves, leaf_seats, valid, s->T, A, Wsm, np2 / Wsm};
+              s->qrange + (long)BLM_QSLOTS * BLM_QSTRIDE * (sim + 1), leaves, leaf_seats, valid, s->T, A, Wsm, np2 / Wsm,
+              (s->cpi && s->cca && s->nk) ? s->cpi : nullptr, s->cca, s->nk, s->exp_table};
     return mlp_launch(p, &f, stream);
 }

@@ -123,6 +123,13 @@ typedef struct {
                             dispatch order changes (e.g. deepest trees first), never a result */
     int prio_thresh;     /* > 0: bl_sim_expand raises the wave priority of envs whose previous descent (path[0]) was at
                             least this long; 0: off */
+    /* Compacted policy rows, written by whoever stores a node's logits (bl_sim_finish, bl_sim_infer_finish, bl_sim_backup,
+     * bl_sim_plant_root, bl_sim_compact) and read by bl_sim_expand instead of logits[b,t,:] / children[b,t,:]: the actions
+     * with expf(logit) != 0 in ascending order (the others add +-0 to the Newton sums of cuda.cu:35-68 and are never drawn).
+     * All three NULL: bl_sim_expand runs its general kernel on logits/children. */
+    float* cpi;          /* f32 (B,T,A): cpi[b,t,j] = expf(logit of the j-th kept action) (host libm's, via exp_table) */
+    uint32_t* cca;       /* u32 (B,T,A): child << 16 | action; child 0xffff = not expanded yet (bl_sim_expand fills it in) */
+    int16_t* nk;         /* i16 (B,T): kept actions per node; bl_sim_init zeroes it */
 } bl_search_t;
 
 /* mcts/__init__.py:113-129 + hex/__init__.py:148-195 for simulation number `sim` (1..T-1):
@@ -184,6 +191,18 @@ int bl_rezero_relu_f32(const float* x, const float* y, const float* alpha, float
  * scattered by seat, both rounded to f16 into node 0 of s->logits / s->v.  The caller then sets its sim counter to 1. */
 int bl_sim_plant_root(const bl_search_t* s, const float* policy_raw, const float* value_raw /*(B)*/, const uint8_t* valid,
                       const int32_t* seats /*(B)*/, const float* draw, float eps, bl_stream_t stream);
+
+/* Builds the compacted rows (cpi, cca, nk) of node leaves[b] of every env -- node 0 when leaves is NULL -- from
+ * logits[b,node,:]; for logits stored without one of the calls above (MCTS.plant_root's tensor assignment). */
+int bl_sim_compact(const bl_search_t* s, const int16_t* leaves /*(B) or NULL*/, bl_stream_t stream);
+
+/* Device self-test, call once per process outside any stream capture (synchronises `stream`).  bl_sim_expand's serial
+ * folds pad every dependent DPP step with the 2 wait states the ISA asks for (`s_nop 1`); on gfx950 one (`s_nop 0`) is
+ * measured to be enough and 30 % faster.  This runs both variants on 4096 waves x 108 random chains against a serial
+ * sum and switches the library to the one-wait-state fold only if it reproduced every prefix total (and BL_FOLD_SAFE is
+ * not set).  Returns the number of wrong totals of the fast variant (0 = in use), or a BL_E* code. */
+int bl_selftest(bl_stream_t stream);
+int bl_fold_variant(void);   /* 1: one-wait-state fold in use; 0: ISA-padded fold */
 
 /* MCTS.n_leaves (mcts/__init__.py:151-152): per env, nodes with parents != -1 that no node names as its parent. */
 int bl_sim_n_leaves(const bl_search_t* s, long long* out /*i64 (B)*/, bl_stream_t stream);

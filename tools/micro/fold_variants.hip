@@ -34,14 +34,19 @@ template <int MODE> __global__ void fold(const float* s, const float* g, float* 
             if (MODE == 4) asm volatile(R16("v_add_f32_dpp %0, %0, %1 " WS "\n s_nop 1\n") : "+v"(x) : "v"(ts));
             if (MODE == 5) asm volatile(R16("v_add_f32_dpp %0, %0, %2 " RS "\n v_add_f32_dpp %1, %1, %3 " RS "\n") : "+v"(x), "+v"(y) : "v"(ts), "v"(tg));
             if (MODE == 6) asm volatile(R16("v_add_f32_dpp %0, %0, %2 " RS "\n v_mov_b32 %1, %2\n") : "+v"(x), "+v"(z) : "v"(ts));
+            // lanes 0..31 only (EXEC upper half clear): does a half-empty wave64 VALU op retire sooner?
+            if (MODE == 7) asm volatile("s_mov_b64 s[20:21], exec\n s_mov_b64 exec, 0xffffffff\n" R16("v_add_f32_dpp %0, %0, %1 " RS "\n s_nop 0\n") "s_mov_b64 exec, s[20:21]\n" : "+v"(x) : "v"(ts) : "s20", "s21");
+            if (MODE == 8) asm volatile("s_mov_b64 s[20:21], exec\n s_mov_b64 exec, 0xffffffff\n" R16("v_add_f32_dpp %0, %0, %1 " RS "\n") "s_mov_b64 exec, s[20:21]\n" : "+v"(x) : "v"(ts) : "s20", "s21");
+            if (MODE == 9) asm volatile("s_mov_b64 s[20:21], exec\n s_mov_b64 exec, 0xffff\n" R16("v_add_f32_dpp %0, %0, %1 " RS "\n s_nop 0\n") "s_mov_b64 exec, s[20:21]\n" : "+v"(x) : "v"(ts) : "s20", "s21");
         }
     }
     if (threadIdx.x == 0) cyc[blockIdx.x] = clock64() - t0;
     os[i] = x; og[i] = (MODE == 0 || MODE == 5) ? y : z;
 }
 
-static const char* NAMES[7] = {"A 2ch wave_shr        ", "B 1ch row_shr +nop1   ", "C 1ch row_shr +nop0   ", "D 1ch row_shr bare    ",
-                               "E 1ch wave_shr +nop1  ", "F 2ch row_shr         ", "G 1ch row_shr +v_mov  "};
+static const char* NAMES[10] = {"A 2ch wave_shr        ", "B 1ch row_shr +nop1   ", "C 1ch row_shr +nop0   ", "D 1ch row_shr bare    ",
+                               "E 1ch wave_shr +nop1  ", "F 2ch row_shr         ", "G 1ch row_shr +v_mov  ",
+                               "H 1ch row_shr nop0 lo32", "I 1ch row_shr bare lo32", "J 1ch row_shr nop0 lo16"};
 
 template <int MODE> void run(int W, const float* s, const float* g, float* os, float* og, long long* cyc, const std::vector<float>& hs,
                              const std::vector<float>& hg) {
@@ -53,13 +58,14 @@ template <int MODE> void run(int W, const float* s, const float* g, float* os, f
     hipMemcpy(rs.data(), os, N * 4, hipMemcpyDeviceToHost); hipMemcpy(rg.data(), og, N * 4, hipMemcpyDeviceToHost);
     hipMemcpy(hc.data(), cyc, W * 8, hipMemcpyDeviceToHost);
     const bool row = !(MODE == 0 || MODE == 4), two = (MODE == 0 || MODE == 5);
+    const int lanes = MODE == 7 || MODE == 8 ? 32 : (MODE == 9 ? 16 : 64);
     long bad = 0;
     for (int w = 0; w < W; w++) {
         volatile float a = 0.f, b = 0.f;
         for (int l = 0; l < 64; l++) {
             if (row && (l % 16) == 0) { a = 0.f; b = 0.f; }
             a = a + hs[w * 64 + l]; b = b + hg[w * 64 + l];
-            if (a != rs[w * 64 + l]) bad++;
+            if (l < lanes && a != rs[w * 64 + l]) bad++;
             if (two && b != rg[w * 64 + l]) bad++;
         }
     }
@@ -78,7 +84,7 @@ int main() {
     for (int W : {1, 1024, 4096, 8192}) {
         run<0>(W, s, g, os, og, cyc, hs, hg); run<1>(W, s, g, os, og, cyc, hs, hg); run<2>(W, s, g, os, og, cyc, hs, hg);
         run<3>(W, s, g, os, og, cyc, hs, hg); run<4>(W, s, g, os, og, cyc, hs, hg); run<5>(W, s, g, os, og, cyc, hs, hg);
-        run<6>(W, s, g, os, og, cyc, hs, hg);
+        run<6>(W, s, g, os, og, cyc, hs, hg); run<7>(W, s, g, os, og, cyc, hs, hg); run<8>(W, s, g, os, og, cyc, hs, hg); run<9>(W, s, g, os, og, cyc, hs, hg);
     }
     return 0;
 }
