@@ -19,7 +19,7 @@ class Search(ctypes.Structure):
     _fields_ = [(k, _vp) for k in ('logits', 'v', 'w', 'n', 'children', 'parents', 'relation', 'rewards', 'terminal',
                                    'boards', 'seats', 'c_puct', 'qrange', 'exp_table')] + \
                [('B', _i), ('T', _i), ('boardsize', _i), ('obs_f16', _i), ('path', _vp), ('order', _vp), ('prio_thresh', _i),
-                ('cpi', _vp), ('cca', _vp), ('nk', _vp)]
+                ('cpi', _vp), ('cca', _vp), ('nk', _vp), ('fav', _vp)]
 
 
 SYMBOLS = {

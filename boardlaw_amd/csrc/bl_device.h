@@ -149,6 +149,7 @@ struct Search {
     uint16_t* rewards; uint8_t* terminal; uint8_t* boards; int32_t* seats; const uint16_t* c_puct; uint32_t* qrange;
     const float* exp_table; int B, T, S; int obs_f16; int16_t* path; const int32_t* order; int prio_thresh;
     float* cpi; uint32_t* cca; int16_t* nk;      // compacted policy rows, see compact_store()
+    int16_t* fav;                                // (B,T) most visited child of a node, a hint for bl_expand.hip's speculative batches
 };
 
 // ------------------------------------------------------------------------------------------------------------------

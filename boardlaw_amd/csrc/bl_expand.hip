@@ -86,22 +86,40 @@ __device__ __forceinline__ void fold_block(float& x, const float t, const int m)
 __device__ __forceinline__ int bperm_i(int src_lane, int v) { return __builtin_amdgcn_ds_bpermute(src_lane << 2, v); }
 
 // ------------------------------------------------------------------------------------------------------------------
-// RMAX: blocks of 32 kept actions a node can have (ceil(A / 32));  KT: registers of node slots (ceil(T / 64)).
+// RMAX: blocks of 32 kept actions a node can have (ceil(A / 32));  KT: registers of node slots (ceil(T / 64));
+// NW: waves per env.
+//
+// NW > 1 -- speculative batches.  What policy() computes at a node (the Newton solve and the drawn edge: the uniform is
+// rands[b, node]) depends on that node alone, not on how the descent got there.  So the NW waves of an env (one per
+// SIMD) evaluate, at the same time, the current node and its most likely continuation u1 = fav[u0], u2 = fav[u1], ...
+// (fav[t] = t's most visited child, kept up to date below); the descent then follows the drawn edges through the results
+// for as long as they match the guesses, and starts the next batch at the first node that was not guessed.  A guess is
+// only ever a hint: every level's result is the exact evaluation of the node the descent is at.  Measured on the bench
+// workload (MI355X, 9x9, 4096 envs x 64 sims): one wave per env 64 us per launch, two waves 57 us, four waves 82 us --
+// 16384 waves no longer fit the chip's 8192 wave slots -- and guessing from the first level on beats waiting for the
+// descent to get deep (`deep_thresh` 0 / 3 / 5 / 8: 57 / 62 / 65 / 69 us): a wasted guess costs nothing that matters,
+// the kernel is bound by the latency of its longest descent, not by VALU throughput.
 // ------------------------------------------------------------------------------------------------------------------
-template <int RMAX, int KT, bool FAST, bool COUNT>
-__global__ void __launch_bounds__(BL_WAVE) sim_expand2_kernel(Search s, int sim, const uint16_t* rands, int16_t* leaves_out,
-                                                              void* obs_out, uint8_t* valid_out, int32_t* leaf_seats_out,
-                                                              unsigned long long* counters) {
+template <int RMAX, int KT, bool FAST, bool COUNT, int NW>
+__global__ void __launch_bounds__(BL_WAVE * NW) sim_expand2_kernel(Search s, int sim, const uint16_t* rands, int16_t* leaves_out,
+                                                                   void* obs_out, uint8_t* valid_out, int32_t* leaf_seats_out,
+                                                                   unsigned long long* counters, int deep_thresh) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    __shared__ int res[2][NW][4];
     uint8_t* cells = (uint8_t*)smem;
     const int S = s.S, A = S * S, T = s.T;
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int slot = blockIdx.x;
     const int b = s.order ? s.order[slot] : slot;
     const long envbase = (long)b * T;
     const bool lowhalf = lane < 32;
     const int el = lane & 31;
     int16_t* path = s.path ? s.path + (long)b * (T + 2) : nullptr;
+    // Which descent of which env goes deep cannot be told in advance (most envs own a long most-visited line, and a
+    // descent's length is mostly decided by where it leaves that line), so every env keeps its helper waves; they sleep
+    // at the batch barrier and guesses are evaluated only from level `deep_thresh` on, where a descent that is still
+    // going is likely to go on -- the short majority never pays for a wasted guess.
+    const int E = NW;
     if (s.prio_thresh > 0 && path) {
         // s_setprio ignores EXEC: the condition has to be an SGPR compare (readfirstlane), not a divergent branch
         if (__builtin_amdgcn_readfirstlane((int)path[0]) >= s.prio_thresh) __builtin_amdgcn_s_setprio(3);
@@ -114,15 +132,17 @@ __global__ void __launch_bounds__(BL_WAVE) sim_expand2_kernel(Search s, int sim,
     int nn[KT];           // n[b,t]
     int info[KT];         // nk | seat << 16 | terminal << 17
     int rd[KT];           // rand[b,t] (f16 bits)
+    int fav[KT];          // most visited child of slot t, or -1
 #pragma unroll
     for (int kt = 0; kt < KT; kt++) {
         const int tt = kt * 64 + lane;
-        wp[kt] = 0; nn[kt] = 0; info[kt] = 0; rd[kt] = 0;
+        wp[kt] = 0; nn[kt] = 0; info[kt] = 0; rd[kt] = 0; fav[kt] = -1;
         if (tt < T) {
             wp[kt] = *(const uint32_t*)(s.w + (envbase + tt) * 2);
             nn[kt] = s.n[envbase + tt];
             info[kt] = (int)(uint16_t)s.nk[envbase + tt] | ((s.seats[envbase + tt] & 1) << 16) | ((s.terminal[envbase + tt] ? 1 : 0) << 17);
             rd[kt] = rands[envbase + tt];
+            if (NW > 1) fav[kt] = s.fav[envbase + tt];
         }
     }
     float lo, hi;
@@ -130,35 +150,24 @@ __global__ void __launch_bounds__(BL_WAVE) sim_expand2_kernel(Search s, int sim,
     const float rden = hi - lo + 1.e-4f;
     const float cpuct = h2f(s.c_puct[b]);
 
-    auto slot_info = [&](int t) {
+    auto pick = [&](const int (&regs)[KT], int t) {       // regs[t], t wave-uniform
         int v = 0;
 #pragma unroll
-        for (int kt = 0; kt < KT; kt++) if ((t >> 6) == kt) v = __builtin_amdgcn_readlane(info[kt], t & 63);
-        return v;
-    };
-    auto slot_rand = [&](int t) {
-        int v = 0;
-#pragma unroll
-        for (int kt = 0; kt < KT; kt++) if ((t >> 6) == kt) v = __builtin_amdgcn_readlane(rd[kt], t & 63);
-        return h2f((uint16_t)v);
+        for (int kt = 0; kt < KT; kt++) if ((t >> 6) == kt) v = __builtin_amdgcn_readlane(regs[kt], t & 63);
+        return __builtin_amdgcn_readfirstlane(v);
     };
 
-    // ---- descend_kernel's loop, cuda.cu:138-182
-    int t = 0, parent = 0, action = -1, nlev = 0, sel_e = 0;
-    int tinfo = __builtin_amdgcn_readfirstlane(slot_info(0));
-    bool live = true;
-    for (int depth = 0; depth < T; depth++) {
-        if (!live || t == -1 || ((tinfo >> 17) & 1)) break;
-        if (path && lane == 0) path[1 + depth] = (int16_t)t;
-        nlev = depth + 1;
+    // policy() + the draw at node `t` (cuda.cu:70-99, 35-68, 157-176): returns the drawn action (-1: none has positive
+    // probability), its child slot (-1: not expanded) and its index in t's compacted row.
+    auto evaluate = [&](const int t, const int tinfo, int& action_o, int& child_o, int& sel_o, int& iters_o, int& nch_o) {
         long long tp0 = 0;
         if (COUNT) tp0 = clock64();
-        const int nk = __builtin_amdgcn_readfirstlane(tinfo & 0xffff), seat = __builtin_amdgcn_readfirstlane((tinfo >> 16) & 1);
+        const int nk = tinfo & 0xffff, seat = (tinfo >> 16) & 1;
         const int R = (nk + 31) >> 5;
-        const float rnd = slot_rand(t);
+        const float rnd = h2f((uint16_t)pick(rd, t));
         const long row = (envbase + t) * A;
 
-        // policy(), cuda.cu:70-99, on the node's kept actions: element e = 32 r + (lane & 31), in both halves of the wave
+        // element e = 32 r + (lane & 31) of the node's kept actions, in both halves of the wave
         float top[RMAX], q[RMAX], term[RMAX], x[RMAX];
         uint32_t cc[RMAX];
         bool in[RMAX];
@@ -256,25 +265,89 @@ __global__ void __launch_bounds__(BL_WAVE) sim_expand2_kernel(Search s, int sim,
             }
         }
         if (sel_r < 0) { sel_r = last_r; sel_lane = last_lane; }
-        parent = t;
-        if (COUNT) {
-            const int nc = wave_sum_i32(nch);
-            if (lane == 0) {
-                unsigned long long* e = counters + 12 * (long)b;
-                e[0] += 1; e[1] += iters; if ((unsigned long long)iters > e[2]) e[2] = iters; e[3] += nc;
+        iters_o = iters;
+        nch_o = COUNT ? wave_sum_i32(nch) : 0;
+        action_o = -1; child_o = -1; sel_o = 0;
+        if (sel_r >= 0) {
+            uint32_t ccs = 0;
+#pragma unroll
+            for (int r = 0; r < RMAX; r++) if (r == sel_r) ccs = (uint32_t)__builtin_amdgcn_readlane((int)cc[r], sel_lane);
+            action_o = (int)(ccs & 0xffffu);
+            sel_o = 32 * sel_r + (sel_lane & 31);
+            child_o = __builtin_amdgcn_readfirstlane((int)(int16_t)(ccs >> 16));
+        }
+    };
+
+    // ---- descend_kernel's loop, cuda.cu:138-182, a batch of up to E guessed levels at a time
+    int t = 0, parent = 0, action = -1, nlev = 0, sel_e = 0, evals = 0;
+    int tinfo = pick(info, 0);
+    bool live = true;
+    for (int batch = 0; batch < T; batch++) {
+        if (!live || t == -1 || ((tinfo >> 17) & 1) || nlev >= T) break;
+        // the nodes of this batch: the current one and its guessed continuation
+        int u[NW], uinfo[NW];
+        u[0] = t; uinfo[0] = tinfo;
+#pragma unroll
+        for (int k = 1; k < NW; k++) {
+            u[k] = -1; uinfo[k] = 0;
+            if (nlev >= deep_thresh && u[k - 1] != -1 && !((uinfo[k - 1] >> 17) & 1)) {
+                u[k] = pick(fav, u[k - 1]);
+                if (u[k] != -1) uinfo[k] = pick(info, u[k]);
             }
         }
-        if (sel_r < 0) { action = -1; live = false; break; }     // no action with positive probability: the reference would index [-1]
-        uint32_t ccs = 0;
+        int my = -1, myinfo = 0;
 #pragma unroll
-        for (int r = 0; r < RMAX; r++) if (r == sel_r) ccs = (uint32_t)__builtin_amdgcn_readlane((int)cc[r], sel_lane);
-        action = (int)(ccs & 0xffffu);
-        sel_e = 32 * sel_r + (sel_lane & 31);
-        t = __builtin_amdgcn_readfirstlane((int)(int16_t)(ccs >> 16));
-        if (t != -1) tinfo = __builtin_amdgcn_readfirstlane(slot_info(t));
+        for (int k = 0; k < NW; k++) if (wave == k) { my = u[k]; myinfo = uinfo[k]; }
+        int ra = -2, rc = -1, rs = 0, ri = 0, rn = 0;
+        if (my != -1 && !((myinfo >> 17) & 1)) { evaluate(my, myinfo, ra, rc, rs, ri, rn); evals++; }
+        if (NW > 1 && E > 1) {
+            if (lane == 0) { res[batch & 1][wave][0] = ra; res[batch & 1][wave][1] = rc; res[batch & 1][wave][2] = rs; res[batch & 1][wave][3] = ri | (rn << 8); }
+            __syncthreads();
+        }
+        // follow the drawn edges through the batch
+#pragma unroll
+        for (int k = 0; k < NW; k++) {
+            if (k < E) {
+                int a_k = ra, c_k = rc, s_k = rs, in_k = ri | (rn << 8);
+                if (NW > 1 && E > 1) {
+                    a_k = __builtin_amdgcn_readfirstlane(res[batch & 1][k][0]); c_k = __builtin_amdgcn_readfirstlane(res[batch & 1][k][1]);
+                    s_k = __builtin_amdgcn_readfirstlane(res[batch & 1][k][2]); in_k = __builtin_amdgcn_readfirstlane(res[batch & 1][k][3]);
+                }
+                const int node = u[k];
+                if (path && wave == 0 && lane == 0) path[1 + nlev] = (int16_t)node;
+                nlev++;
+                parent = node; sel_e = s_k;
+                if (COUNT && wave == 0 && lane == 0) {
+                    unsigned long long* e = counters + 12 * (long)b;
+                    const int iters = in_k & 0xff;
+                    e[0] += 1; e[1] += iters; if ((unsigned long long)iters > e[2]) e[2] = iters; e[3] += in_k >> 8;
+                }
+                if (a_k < 0) { action = -1; live = false; break; }       // no action with positive probability: the reference would index [-1]
+                action = a_k;
+                if (NW > 1) {
+                    // node's most visited child once this descent is backed up: the drawn child gains a visit (n += 2)
+                    const int cnew = c_k == -1 ? sim : c_k;
+                    const int f_old = pick(fav, node);
+                    if (f_old == -1 || pick(nn, cnew) + 2 >= pick(nn, f_old)) {
+#pragma unroll
+                        for (int kt = 0; kt < KT; kt++) if ((node >> 6) == kt && lane == (node & 63)) fav[kt] = cnew;
+                    }
+                }
+                t = c_k;
+                if (t == -1) break;
+                tinfo = pick(info, t);
+                if ((tinfo >> 17) & 1) break;
+                if (!(k + 1 < E && k + 1 < NW && u[k + 1 < NW ? k + 1 : 0] == t)) break;     // the guess ends here: next batch starts at t
+            }
+        }
     }
+    if (NW > 1 && wave > 0) return;
     if (action < 0) action = 0;
     if (COUNT) tk1 = clock64();
+    if (NW > 1) {
+#pragma unroll
+        for (int kt = 0; kt < KT; kt++) if (kt * 64 + lane < T) s.fav[envbase + kt * 64 + lane] = (int16_t)fav[kt];
+    }
 
     // ---- leaves = children[envs, parents, actions]; leaves[leaves == -1] = sim   (mcts/__init__.py:117-122)
     const int nxt = t;
@@ -321,7 +394,7 @@ __global__ void __launch_bounds__(BL_WAVE) sim_expand2_kernel(Search s, int sim,
         unsigned long long* e = counters + 12 * (long)b;
         const long long tk2 = clock64();
         e[4] += tsetup; e[5] += tterms; e[6] += tfold; e[7] += tupd;
-        e[8] += tk1 - tk0; e[9] += tk2 - tk1;
+        e[8] += tk1 - tk0; e[9] += tk2 - tk1; e[10] += evals;
     }
 }
 
@@ -383,27 +456,31 @@ __global__ void __launch_bounds__(BL_WAVE) fold_selftest_kernel(uint32_t seed, i
 using namespace bl;
 
 // Launches the compact-row kernel; returns BL_ETOOBIG when the shape is outside its template set (the caller then uses
-// the general kernel of bl_kernels.hip).
+// the general kernel of bl_kernels.hip).  waves: 1, or 4 = speculative batches for envs whose last descent had at least
+// `deep_thresh` nodes (needs s.fav).
 int bl_expand2_launch(const Search& ss, int sim, const void* rands, int16_t* leaves, void* obs, uint8_t* valid, int32_t* leaf_seats,
-                      unsigned long long* counters, int fast, hipStream_t stream) {
+                      unsigned long long* counters, int fast, int waves, int deep_thresh, hipStream_t stream) {
     const int A = ss.S * ss.S, T = ss.T;
     if (!ss.cpi || !ss.cca || !ss.nk || A > 384 || T > 256) return BL_ETOOBIG;
+    if ((waves != 4 && waves != 2) || !ss.fav) waves = 1;
     const int need = (A + 31) / 32;
     const int rmax = need <= 1 ? 1 : need <= 2 ? 2 : need <= 3 ? 3 : need <= 6 ? 6 : 12;
     const int kt = T <= 64 ? 1 : 4;
     const size_t lds = (size_t)al16(A);
-    const dim3 grid(ss.B), block(64);
-#define BLX_LAUNCH(R_, K_, F_, C_) hipLaunchKernelGGL((sim_expand2_kernel<R_, K_, F_, C_>), grid, block, lds, stream, ss, sim, \
-                                                      (const uint16_t*)rands, leaves, obs, valid, leaf_seats, counters)
-#define BLX_MODE(R_, K_) { if (counters) BLX_LAUNCH(R_, K_, true, true); else if (fast) BLX_LAUNCH(R_, K_, true, false); else BLX_LAUNCH(R_, K_, false, false); }
-#define BLX_KT(R_) { if (kt == 1) BLX_MODE(R_, 1) else BLX_MODE(R_, 4) }
+    const dim3 grid(ss.B), block(64 * waves);
+#define BLX_LAUNCH(R_, K_, F_, C_, W_) hipLaunchKernelGGL((sim_expand2_kernel<R_, K_, F_, C_, W_>), grid, block, lds, stream, ss, sim, \
+                                                          (const uint16_t*)rands, leaves, obs, valid, leaf_seats, counters, deep_thresh)
+#define BLX_MODE(R_, K_, W_) { if (counters) BLX_LAUNCH(R_, K_, true, true, W_); else if (fast) BLX_LAUNCH(R_, K_, true, false, W_); else BLX_LAUNCH(R_, K_, false, false, W_); }
+#define BLX_KT(R_, W_) { if (kt == 1) BLX_MODE(R_, 1, W_) else BLX_MODE(R_, 4, W_) }
+#define BLX_W(R_) { if (waves == 4) BLX_KT(R_, 4) else if (waves == 2) BLX_KT(R_, 2) else BLX_KT(R_, 1) }
     switch (rmax) {
-        case 1: BLX_KT(1) break;
-        case 2: BLX_KT(2) break;
-        case 3: BLX_KT(3) break;
-        case 6: BLX_KT(6) break;
-        default: BLX_KT(12) break;
+        case 1: BLX_W(1) break;
+        case 2: BLX_W(2) break;
+        case 3: BLX_W(3) break;
+        case 6: BLX_W(6) break;
+        default: BLX_W(12) break;
     }
+#undef BLX_W
 #undef BLX_KT
 #undef BLX_MODE
 #undef BLX_LAUNCH

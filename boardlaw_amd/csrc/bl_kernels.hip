@@ -998,6 +998,8 @@ __global__ void __launch_bounds__(256) sim_init_kernel(Search s, const uint8_t* 
     grid_fill(s.terminal, B * T, 0);
     grid_fill(s.qrange, (T + 1) * (size_t)BL_QWORDS * sizeof(uint32_t), 0);
     if (s.nk) grid_fill(s.nk, B * T * 2, 0);
+    if (s.fav) grid_fill(s.fav, B * T * 2, 0xffff);
+    if (s.path) { const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x; if (tid < B) s.path[tid * (T + 2)] = 0; }   // no previous descent
 }
 
 // worlds = stack([world] * T) (mcts/__init__.py:62): every node slot of env b starts as a copy of the root board and
@@ -1101,7 +1103,7 @@ static int check_launch() { return hipGetLastError() == hipSuccess ? BL_OK : BL_
     }
 
 int bl_expand2_launch(const Search& ss, int sim, const void* rands, int16_t* leaves, void* obs, uint8_t* valid, int32_t* leaf_seats,
-                      unsigned long long* counters, int fast, hipStream_t stream);     // bl_expand.hip
+                      unsigned long long* counters, int fast, int waves, int deep_thresh, hipStream_t stream);     // bl_expand.hip
 int bl_fold_selftest(int use_fast, hipStream_t stream);
 
 extern "C" {
@@ -1254,7 +1256,7 @@ static Search to_search(const bl_search_t* s) {
     return Search{(uint16_t*)s->logits, (uint16_t*)s->v, (uint16_t*)s->w, s->n, s->children, s->parents, s->relation,
                   (uint16_t*)s->rewards, s->terminal, s->boards, s->seats, (const uint16_t*)s->c_puct, s->qrange,
                   s->exp_table, s->B, s->T, s->boardsize, s->obs_f16, s->path, s->order, s->prio_thresh,
-                  s->cpi, s->cca, s->nk};
+                  s->cpi, s->cca, s->nk, s->fav};
 }
 
 // 1 once bl_selftest() has verified the one-wait-state fold on this device; BL_FOLD_SAFE=1 keeps the padded variant.
@@ -1271,7 +1273,9 @@ static int sim_expand_impl(const bl_search_t* s, int sim, const void* rands, int
     if (!legacy && !forced_group() && s->cpi && s->cca && s->nk) {
         // compacted rows + node statistics in registers + one DPP chain per level (bl_expand.hip); shapes outside its
         // template set (A > 384 or T > 256) fall through to the general kernel
-        rc = bl_expand2_launch(to_search(s), sim, rands, leaves, obs, valid, leaf_seats, counters, g_fold_fast, (hipStream_t)stream);
+        static const int waves = getenv("BL_EXPAND_WAVES") ? atoi(getenv("BL_EXPAND_WAVES")) : 2;
+        static const int deep = getenv("BL_EXPAND_DEEP") ? atoi(getenv("BL_EXPAND_DEEP")) : 0;
+        rc = bl_expand2_launch(to_search(s), sim, rands, leaves, obs, valid, leaf_seats, counters, g_fold_fast, waves, deep, (hipStream_t)stream);
         if (rc != BL_ETOOBIG) return rc;
     }
     const int G = pick_group(s->B, A), K = pick_k(A, G);

@@ -136,6 +136,7 @@ class MCTS:
             self._cpi = e(B, T, A, dtype=torch.float)
             self._cca = e(B, T, A, dtype=torch.int32)
             self._nk = e(B, T, dtype=torch.short)
+            self._fav = e(B, T, dtype=torch.short)
             self.counters = torch.zeros((B, 12), dtype=torch.int64, device=dev) if count else None
             self._search = _native.Search(
                 logits=self.decisions.logits.data_ptr(), v=self.decisions.v.data_ptr(), w=self.stats.w.data_ptr(),
@@ -144,7 +145,8 @@ class MCTS:
                 terminal=self.transitions.terminal.data_ptr(), boards=self.worlds.board.data_ptr(),
                 seats=self.worlds.seats.data_ptr(), c_puct=self.c_puct.data_ptr(), qrange=self._qrange.data_ptr(),
                 exp_table=self._exp.data_ptr(), B=B, T=T, boardsize=bs, obs_f16=int(obs_half),
-                path=self._path.data_ptr(), cpi=self._cpi.data_ptr(), cca=self._cca.data_ptr(), nk=self._nk.data_ptr())
+                path=self._path.data_ptr(), cpi=self._cpi.data_ptr(), cca=self._cca.data_ptr(), nk=self._nk.data_ptr(),
+                fav=self._fav.data_ptr())
             with torch.cuda.device(dev):
                 _native.check(_native.lib().bl_sim_init(ctypes.byref(self._search), world.board.contiguous().data_ptr(),
                                                         world.seats.int().contiguous().data_ptr(), _native.stream(dev)))

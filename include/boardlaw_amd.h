@@ -130,6 +130,9 @@ typedef struct {
     float* cpi;          /* f32 (B,T,A): cpi[b,t,j] = expf(logit of the j-th kept action) (host libm's, via exp_table) */
     uint32_t* cca;       /* u32 (B,T,A): child << 16 | action; child 0xffff = not expanded yet (bl_sim_expand fills it in) */
     int16_t* nk;         /* i16 (B,T): kept actions per node; bl_sim_init zeroes it */
+    int16_t* fav;        /* i16 (B,T) scratch or NULL: each node's most visited child (-1: none), maintained by bl_sim_expand as
+                            the guess for its speculative batches (several levels of a deep descent evaluated at once, one per
+                            wave); a hint only -- results never depend on it.  NULL: one level at a time */
 } bl_search_t;
 
 /* mcts/__init__.py:113-129 + hex/__init__.py:148-195 for simulation number `sim` (1..T-1):
