@@ -222,12 +222,12 @@ __device__ __forceinline__ int policy_eval(const Tree& m, int b, int t, int seat
 // filling each other's DPP wait states.
 // ------------------------------------------------------------------------------------------------------------------
 
-// One step of both chains.  The ISA asks for 2 wait states between a VALU write and a DPP read of the same VGPR; each
-// chain's next step is separated from its previous one by the other chain's instruction.  tools/micro/dpp_hazard.hip
-// measures that this one intervening VALU instruction is sufficient on gfx950 (0 wrong lanes in 2e8; back-to-back
-// steps of ONE chain do fail), and the in-order VALU pipeline makes that timing independent of other waves; an extra
-// s_nop per step costs 35 % of the fold.
-#define BL_FOLD_STEP "v_add_f32_dpp %0, %0, %2 wave_shr:1 row_mask:0xf bank_mask:0xf\n\tv_add_f32_dpp %1, %1, %3 wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+// One step of both chains.  The ISA asks for 2 wait states between a VALU write and a DPP read of the same VGPR (there is
+// no interlock): each chain's next step is separated from its previous one by the other chain's instruction plus one
+// s_nop.  (tools/micro/dpp_hazard.hip measures that the other chain's instruction alone is enough on gfx950; this
+// general kernel -- bl_mcts_descend/root, bl_sim_root, and bl_sim_expand outside bl_expand.hip's shapes -- does not rely
+// on it.  The hot path's fold lives in bl_expand.hip and picks its padding after a device self-test.)
+#define BL_FOLD_STEP "v_add_f32_dpp %0, %0, %2 wave_shr:1 row_mask:0xf bank_mask:0xf\n\tv_add_f32_dpp %1, %1, %3 wave_shr:1 row_mask:0xf bank_mask:0xf\n\ts_nop 0\n\t"
 // 8 fold steps of both chains.  The leading s_nop covers the VALU-write -> DPP-read hazard against whatever wrote x/y.
 #define BL_FOLD8(x, y, ts, tg)                                                                              \
     asm volatile("s_nop 1\n\t" BL_FOLD_STEP BL_FOLD_STEP BL_FOLD_STEP BL_FOLD_STEP BL_FOLD_STEP BL_FOLD_STEP \

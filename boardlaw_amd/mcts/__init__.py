@@ -341,11 +341,31 @@ class MCTSAgent:
     eval) and replays it: the search has no host-side decision in it (the fused path keeps `sim` on the host and never
     syncs), so replay removes every launch gap.  Random draws come from torch's generator exactly as in eager mode."""
 
+    # kwargs of the reference's MCTS (mcts/__init__.py:29): the only ones a checkpoint carries
+    REFERENCE_KWARGS = ('n_nodes', 'c_puct', 'noise_eps', 'alpha_scale')
+    GRAPH_CACHE_BYTES = 8 << 30     # captured moves kept alive (each owns a whole tree): least recently used go first
+
     def __init__(self, network, graph=False, **kwargs):
         self.network = network
         self.kwargs = kwargs
         self.graph = graph
-        self._graphs = {}
+        self._graphs = {}           # insertion-ordered: oldest use first
+
+    def _kwargs_key(self):
+        # the reference mutates agent.kwargs in place (arena: kwargs['n_nodes'] = ...): a captured move belongs to the
+        # kwargs it was captured with
+        return tuple(sorted((k, v if isinstance(v, (int, float, bool, str, type(None))) else id(v)) for k, v in self.kwargs.items()))
+
+    def _graphed(self, key, build):
+        key = key + (self._kwargs_key(),)
+        g = self._graphs.pop(key, None)
+        if g is None:
+            g = build()
+            used = sum(x.nbytes for x in self._graphs.values())
+            while self._graphs and used + g.nbytes > self.GRAPH_CACHE_BYTES:
+                used -= self._graphs.pop(next(iter(self._graphs))).nbytes
+        self._graphs[key] = g       # most recently used last
+        return g
 
     def _move(self, world, eval, kwargs, clone=True):
         m = mcts(world, self.network, **{**self.kwargs, **kwargs})
@@ -365,9 +385,7 @@ class MCTSAgent:
         if not self.graph or kwargs or world.device.type != 'cuda':
             return self._move(world, eval, kwargs)
         key = (type(world), world.n_envs, world.boardsize, bool(eval), world.device)
-        if key not in self._graphs:
-            self._graphs[key] = _GraphedMove(self, world, eval)
-        return self._graphs[key](world)
+        return self._graphed(key, lambda: _GraphedMove(self, world, eval))(world)
 
     def play(self, world, eval=False):
         """One actor step of the self-play loop (boardlaw/main.py:176-177): decisions = agent(world); new_world,
@@ -379,9 +397,7 @@ class MCTSAgent:
             new_world, transition = world.step(d.actions)
             return d, new_world, transition
         key = ('play', type(world), world.n_envs, world.boardsize, bool(eval), world.device)
-        if key not in self._graphs:
-            self._graphs[key] = _GraphedMove(self, world, eval, step=True)
-        return self._graphs[key](world)
+        return self._graphed(key, lambda: _GraphedMove(self, world, eval, step=True))(world)
 
     def load_state_dict(self, sd):
         self.network.load_state_dict({k[len('network.'):]: v for k, v in sd.items() if k.startswith('network.')})
@@ -389,8 +405,10 @@ class MCTSAgent:
         self._graphs = {}
 
     def state_dict(self):
+        # the reference's checkpoint format (mcts/__init__.py:236-241); its load_state_dict feeds every 'kwargs.*' entry to
+        # MCTS(**kwargs), so this build's own options (rng, graph, fusion switches) stay out of the checkpoint
         return {**{f'network.{k}': v for k, v in self.network.state_dict().items()},
-                **{f'kwargs.{k}': v for k, v in self.kwargs.items()}}
+                **{f'kwargs.{k}': v for k, v in self.kwargs.items() if k in self.REFERENCE_KWARGS}}
 
 
 class _GraphedMove:
@@ -425,6 +443,10 @@ class _GraphedMove:
             with torch.cuda.graph(self.graph):
                 self.out = run()
         self.kind = kind
+        # what this capture keeps alive: the tree and its scratch (the dominant (B,T,A) arrays: logits, children, cpi, cca;
+        # boards; the MoveRng block), estimated from the shapes
+        B, A, T = world.n_envs, world.boardsize ** 2, int({**agent.kwargs}.get('n_nodes', 64))
+        self.nbytes = B * T * (A * 13 + 2 * T + 64)
 
     def __call__(self, world):
         self.board.copy_(world.board); self.seats.copy_(world.seats)

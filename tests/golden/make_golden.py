@@ -193,6 +193,10 @@ def run_search_fixture(mcts_mod, hex_, networks, mcuda, S, B, T, width, depth, n
 
     out = dict(meta=np.array([S, B, T, width, depth, n_moves, seed], np.int64))
     out['world0_board'] = np_(worlds.board); out['world0_seats'] = np_(worlds.seats)
+    # the network itself (SURVEY 8c fixture 3): its state_dict, so that a restated FCModel can be replayed against the
+    # recorded outputs.  Keys as the reference names them (networks.py:10-40), '.' kept, prefixed 'net_state::'.
+    for k, v in net.state_dict().items():
+        out['net_state::' + k] = np_(v)
     ops_all = []
 
     # capture Backup's tensors: patch MCTS.backup to stash them (mcts/__init__.py:97-106)
@@ -231,6 +235,11 @@ def run_search_fixture(mcts_mod, hex_, networks, mcuda, S, B, T, width, depth, n
             out[p + 'rands'] = np.stack(rec.rands)                                     # (T-1,B,T) f16 bits
             out[p + 'net0_logits'] = np_(rnet.calls[0]['logits'])                      # f32, initialize
             out[p + 'net0_v'] = np_(rnet.calls[0]['v'])
+            out[p + 'net0_obs'] = np_(worlds.obs).astype(np.uint8); out[p + 'net0_valid'] = np_(worlds.valid)
+            out[p + 'net0_seats'] = np_(worlds.seats)
+            # the first simulations' network outputs before `.half()` (mcts/__init__.py:135-136): f32 on the CPU path
+            out[p + 'net_logits_f32'] = np.stack([np_(c['logits']) for c in rnet.calls[1:4]])
+            out[p + 'net_v_f32'] = np.stack([np_(c['v']) for c in rnet.calls[1:4]])
             out[p + 'net_logits'] = np.stack([np_(c['logits'].half()) for c in rnet.calls[1:]])  # (T-1,B,A)
             out[p + 'net_v'] = np.stack([np_(c['v'].half()) for c in rnet.calls[1:]])
             out[p + 'net_board'] = np.stack([np_(c['board']) for c in rnet.calls[1:]])  # leaf worlds seen by net

@@ -787,3 +787,114 @@ def test_plant_root_in_one_launch_matches_the_composition(S, B, eps):
 
 def bits16_t(t):
     return t.contiguous().view(torch.int16)
+
+
+# ------------------------------------------------------------------------------------------------ the bench's own launch sequence
+class RecordingRng:
+    """Passes torch's draws through and keeps the descend uniforms, in order."""
+
+    def __init__(self, inner):
+        self.inner, self.rands = inner, []
+
+    def dirichlet(self, alpha, shape):
+        return self.inner.dirichlet(alpha, shape)
+
+    def rand_like(self, x):
+        r = self.inner.rand_like(x)
+        self.rands.append(r)
+        return r
+
+    def categorical(self, logits):
+        return self.inner.categorical(logits)
+
+
+def replay_through_oracle(oracle, board, seats, T, rands_bits, logits_bits, v_bits):
+    """The host search driven by the oracle, fed the GPU's own leaf evaluations: decisions.logits[b, leaf] / decisions.v[b, leaf]
+    are what the network kernels stored for the node created (or re-visited) at that simulation."""
+    s = OracleSearch(oracle, board, seats, T)
+    s.initialize(logits_bits[:, 0], v_bits[:, 0])
+    e = np.arange(board.shape[0])
+    for i in range(T - 1):
+        parents, actions = s.descend(rands_bits[i])
+        leaves, _, _ = s.expand(parents, actions)
+        s.finish(leaves, logits_bits[e, leaves], v_bits[e, leaves])
+    return s
+
+
+def assert_search_equals(m, want):
+    for name, mine, theirs in [('children', m.tree.children, want.children), ('parents', m.tree.parents, want.parents),
+                               ('relation', m.tree.relation, want.relation), ('n', m.stats.n, want.n), ('w', m.stats.w, want.w),
+                               ('rewards', m.transitions.rewards, want.rewards), ('terminal', m.transitions.terminal, want.terminal),
+                               ('boards', m.worlds.board, want.boards), ('seats', m.worlds.seats, want.seats),
+                               ('v', m.decisions.v, want.v), ('logits', m.decisions.logits, want.logits)]:
+        assert np.array_equal(to_np(mine), theirs), name
+    assert np.array_equal(bits16(m.root_probs()), want.root_probs())
+    assert np.array_equal(to_np(m.n_leaves()), want.n_leaves())
+
+
+@pytest.mark.parametrize('S,B,T,width,depth,mode', [(9, 4096, 64, 512, 4, 'eager'), (9, 4096, 64, 512, 4, 'graph'),
+                                                    (13, 1024, 256, 1024, 8, 'eager'), (5, 64, 16, 256, 2, 'graph'),
+                                                    (9, 333, 64, 512, 4, 'eager-torch-gemms')])
+def test_bench_launch_sequence_vs_oracle(oracle, S, B, T, width, depth, mode):
+    """What bench.py times -- bl_sim_plant_root, then T-1 x (bl_sim_expand -> bl_sim_infer_finish) with the real network's
+    fused fp16 plan (13x13/256 nodes: bl_mlp_forward_f16 + bl_sim_finish, the T > 64 route), eagerly with torch's
+    per-simulation uniforms and as a captured HIP graph with MoveRng -- replayed on the host through the oracle, which is
+    handed the uniforms and the leaf evaluations the GPU stored.  Every tree array, visit count, value sum, board and the
+    root distribution must be identical: BASELINE config 2 and config 4's per-GPU shape at full size."""
+    from boardlaw_amd import networks
+    from boardlaw_amd.hex import Hex
+    from boardlaw_amd.mcts import MCTS, MoveRng, TorchRng, mcts
+    board, seats = premixed(oracle, B, S, (S * S) // 3, seed=31 * S + T)
+    world = Hex(board=torch.from_numpy(board).to(DEV), seats=torch.from_numpy(seats).to(DEV))
+    torch.manual_seed(5)
+    net = networks.Inference(networks.FCModel(world.obs_space, world.action_space, width=width, depth=depth).to(DEV),
+                             fused=(mode != 'eager-torch-gemms'))
+    with torch.no_grad():
+        for p_ in net.model.parameters():
+            if p_.ndim == 0:
+                p_.fill_(0.3)          # ReZero gains start at 0: make the evaluation depend on the position
+    net.refresh()
+    if mode == 'graph':
+        rng = MoveRng()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            mcts(world, net, n_nodes=T, rng=rng)          # warm-up outside the capture
+        torch.cuda.current_stream().wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            m = mcts(world, net, n_nodes=T, rng=rng)
+        graph.replay(); graph.replay()                    # the second replay draws fresh uniforms and noise
+        torch.cuda.synchronize()
+        rands = bits16(rng.block)
+    else:
+        rng = RecordingRng(TorchRng())
+        m = mcts(world, net, n_nodes=T, rng=rng)
+        rands = np.stack([bits16(r) for r in rng.rands])
+    assert rands.shape == (T - 1, B, T)
+    want = replay_through_oracle(oracle, board, seats, T, rands, bits16(m.decisions.logits), bits16(m.decisions.v))
+    assert_search_equals(m, want)
+    assert (to_np(m.stats.n)[:, 0] == 2 * (T - 1)).all()
+
+
+def test_fold_wait_states_under_load():
+    """The hot path's serial fold pads each dependent DPP step with ONE wait state where the ISA asks for two (bl_expand.hip).
+    The library only does so after bl_selftest() reproduced every prefix total of random chains with it on this device;
+    here the same check runs > 1e8 fold steps with four waves per SIMD while an MFMA-heavy GEMM stream keeps the matrix
+    pipes and the memory system busy next to it -- no wrong total -- and the ISA-padded variant is exact as well (a
+    failure of that one would return a negative code)."""
+    from boardlaw_amd import _native
+    L = _native.lib()
+    a = torch.randn(4096, 4096, device=DEV, dtype=torch.half)
+    side = torch.cuda.Stream()
+    steps = 0
+    for rep in range(6):
+        with torch.cuda.stream(side):
+            for _ in range(40):
+                a @ a
+        wrong = L.bl_selftest(_native.stream())
+        assert wrong == 0, f'{wrong} wrong prefix totals with the one-wait-state fold'
+        steps += 6 * 4096 * sum((1, 2, 15, 16, 17, 31, 32, 33, 47, 48, 49, 54, 63, 64, 65, 80, 81, 96)) * 2   # both variants
+    torch.cuda.synchronize()
+    assert steps > 1e8
+    assert L.bl_fold_variant() == (0 if os.environ.get('BL_FOLD_SAFE') else 1)

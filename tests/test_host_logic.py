@@ -72,6 +72,20 @@ def test_agent_state_dict_roundtrip_and_dummy_agent():
     other = MCTSAgent(networks.FCModel(heads.Tensor((1,)), heads.Masked(2), width=8, depth=1))
     other.load_state_dict(sd)
     assert other.kwargs == {'n_nodes': 12, 'c_puct': .5}
+    # this build's own options never enter the reference's checkpoint format (its load_state_dict feeds kwargs.* to MCTS())
+    from boardlaw_amd.mcts import MoveRng
+    mine = MCTSAgent(net, graph=True, n_nodes=12, rng=MoveRng(), fuse_finish=False, obs_half=True)
+    assert sorted(k for k in mine.state_dict() if k.startswith('kwargs.')) == ['kwargs.n_nodes']
+    # captured moves are keyed by the kwargs they were captured with and evicted least-recently-used by bytes
+    class G:
+        def __init__(self, n): self.nbytes = n
+    mine.GRAPH_CACHE_BYTES = 100
+    a = mine._graphed(('a',), lambda: G(60)); b = mine._graphed(('b',), lambda: G(30))
+    assert mine._graphed(('a',), lambda: G(60)) is a                   # hit; 'a' is now the most recent
+    c = mine._graphed(('c',), lambda: G(30))                             # 120 > 100: 'b', the least recent, goes
+    assert [k[0] for k in mine._graphs] == ['a', 'c'] and mine._graphed(('b',), lambda: G(30)) is not b
+    mine.kwargs['n_nodes'] = 24                                          # the reference mutates kwargs in place
+    assert mine._graphed(('a',), lambda: G(60)) is not a
     assert all(torch.equal(a, b) for a, b in zip(net.state_dict().values(), other.network.state_dict().values()))
     w = validation.All.initial(n_envs=4, length=3, device='cpu')
     d = DummyAgent(net)(w, eval=True)
