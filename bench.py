@@ -14,8 +14,9 @@ Prints ONE JSON line (rank 0).  Extra objects:
   roofline     the dominant kernel (bl_sim_expand: descend+expand+step+observe), algorithmic bytes per launch (model
                of SURVEY 8d with d,k measured by the kernel's own counters) / its mean duration from HIP events
                recorded around every launch inside the timed region, vs the 8 TB/s HBM peak.
-  cpu_baseline the reference's own CPU kernels (oracle/_ref, kind "reference") or the C oracle (kind "port") driving
-               the same search on a bounded sample (fewer envs, one move) on this host, single thread.
+  cpu_baseline the C oracle (kind "port") driving the same search on this host: one process per physical core with
+               4096/P envs each for ~11 s (sims/s summed; P and nproc stated), plus one process alone and the -O0 build
+               (how the reference JIT-builds its sources) for ns/descent.
 """
 import argparse
 import json
@@ -90,15 +91,15 @@ def total_bytes_per_sim(A, S, T, d, k):
     return d * (4 * A + 5) + 4 * k + (T + 1) / 2 * (2 * S + 2) + (d + 1) * (6 * S + 7) + 13 * A + 6 * S + 19
 
 
-def cpu_baseline(seconds_budget=25.0):
-    """The same search on the host: reference CPU kernels if oracle/_ref is present, else the C oracle."""
+def cpu_baseline(seconds_budget=24.0):
+    """The same search on this box's host cores with the C oracle's kernels (tests/cpu_driver.py): every physical core,
+    one process each, plus a single process and the -O0 build for ns/descent."""
     sys.path.insert(0, os.path.join(ROOT, 'tests'))
     try:
-        import oracle_lib
-        from cpu_driver import run_cpu_search
+        from cpu_driver import run_cpu_baseline
+        return run_cpu_baseline(BOARD, NODES, WIDTH, DEPTH, ENVS, seconds_budget)
     except Exception as e:  # pragma: no cover
-        return {'value': None, 'unit': 'sims/s', 'cores': 1, 'kind': 'port', 'sample': f'unavailable: {e}'}
-    return run_cpu_search(BOARD, NODES, WIDTH, DEPTH, seconds_budget)
+        return {'value': None, 'unit': 'sims/s', 'cores': 0, 'kind': 'port', 'sample': f'unavailable: {type(e).__name__}: {e}'}
 
 
 def respawn_per_gpu(args):
@@ -152,6 +153,7 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--plain-network', action='store_true', help='run the nn.Module under autocast instead of the fp16 inference plan')
     ap.add_argument('--torch-gemms', action='store_true', help='keep the Linears as torch (hipBLASLt) GEMMs instead of the fused MFMA kernel')
+    ap.add_argument('--no-reference-rng', action='store_true', help='skip the second timed region (torch rand_like per simulation)')
     ap.add_argument('--eager', action='store_true', help='launch kernel by kernel instead of replaying a HIP graph per move')
     args = ap.parse_args()
     respawn_per_gpu(args)
@@ -215,6 +217,23 @@ def main():
     sims_total = world * args.envs * NODES * args.steps
     value = sims_total / elapsed
 
+    value_torch_rng = None
+    if world == 1 and not args.eager and not args.no_reference_rng:
+        # the same moves with the reference's RNG protocol: one rand_like (B,T) f16 per simulation (cuda.cu:191) instead of
+        # MoveRng's one block per move -- same amount of randomness, 62 more small launches per move
+        from boardlaw_amd.mcts import TorchRng
+        ref_agent = MCTSAgent(agent.network, n_nodes=NODES, graph=True, rng=TorchRng())
+        w2 = worlds
+        for _ in range(1 + min(args.warmup, 2)):
+            w2 = ref_agent.play(w2)[1]
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            w2 = ref_agent.play(w2)[1]
+        barrier()
+        value_torch_rng = args.envs * NODES * args.steps / (time.perf_counter() - t1)
+        del ref_agent, w2
+
     if rank == 0:
         A, S = BOARD * BOARD, 2
         if not args.eager:
@@ -230,25 +249,31 @@ def main():
         kernel_us = timer.mean_us()
         per_launch = expand_bytes_per_env(A, S, d, k) * args.envs
         achieved = per_launch / (kernel_us * 1e-6) / 1e9
-        traffic = None
-        tpath = os.path.join(ROOT, 'profiles', 'r01_traffic.json')
+        traffic, traffic_source = None, None
+        tpath = os.path.join(ROOT, 'profiles', 'r02_traffic.json')
         if args.envs == ENVS and default_shape and os.path.exists(tpath):
-            # HBM-side bytes per launch from rocprofv3 PMC passes (FETCH_SIZE + WRITE_SIZE), see profiles/README.md
+            # NOT measured in this run: HBM-side bytes per launch from separate rocprofv3 --pmc passes of this very command
+            # (FETCH_SIZE, WRITE_SIZE; calibration and corrections in profiles/README.md), committed with the round
             traffic = json.load(open(tpath))['traffic_bytes_per_launch']
+            traffic_source = 'static: profiles/r02_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `python bench.py`)'
         out = {
             'metric': 'mcts_sims_per_sec', 'value': value, 'unit': 'sims/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps, 'higher_is_better': True,
-            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f16', 'data': 'synthetic',
             'config': {'workload': f'{BOARD}x{BOARD} Hex, {args.envs} envs/GPU x {NODES} sims/move, FCModel {WIDTH}x{DEPTH} fp16 autocast'
                                    + (' (BASELINE config 2)' if default_shape and args.envs == ENVS else ' (NOT the metric\'s configuration)')
                                    + '; step = one self-play move of the batch',
                        'envs_per_gpu': args.envs, 'nodes': NODES, 'boardsize': BOARD, 'parallelism': f'replicas x{world}', 'launch': launch,
+                       'network': ('nn.Module under fp16 autocast' if args.plain_network else 'fp16 inference plan, torch GEMMs (bit-identical to autocast)' if args.torch_gemms
+                                   else 'fused MFMA kernel bl_sim_infer_finish (autocast rounding points; <= 1 f16 ulp vs autocast)') + '; root evaluation fp32',
+                       'rng': 'MoveRng: torch generator, the T-1 descend uniforms of a move drawn as ONE (T-1,B,T) f16 block instead of T-1 rand_like calls',
+                       'value_reference_rng_protocol': value_torch_rng,
                        'd_policy_evals_per_descent': round(d, 3), 'k_child_lookups_per_descent': round(k, 3),
                        'newton_iters_per_eval': round(its, 3),
                        'bytes_per_sim_whole_path': round(total_bytes_per_sim(A, S, NODES, d, k), 1),
                        'hbm_frac_whole_path': total_bytes_per_sim(A, S, NODES, d, k) * value / world / (HBM_PEAK_GBS * 1e9)},
-            'roofline': {'bound': 'hbm', 'kernel': 'bl::sim_expand_kernel', 'achieved': achieved, 'peak': HBM_PEAK_GBS,
-                         'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
+            'roofline': {'bound': 'hbm', 'kernel': 'bl::sim_expand2_kernel (bl_sim_expand)', 'achieved': achieved, 'peak': HBM_PEAK_GBS,
+                         'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic, 'traffic_source': traffic_source,
                          'kernel_us': kernel_us, 'bytes_per_launch': per_launch, 'launches_timed': len(timer.pairs),
                          'timing': 'HIP events around every launch ' + ('inside the timed region' if args.eager else 'in an eager re-run of the same moves right after the timed (graph-replay) region')},
         }

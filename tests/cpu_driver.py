@@ -1,116 +1,120 @@
-"""CPU baseline driver (bench.py's cpu_baseline leg and nothing else): the same search loop as the product, run on the
-host with the reference's own CPU kernels (oracle/_ref/*.so, the reference's unmodified sources compiled by
-oracle/Makefile) when present, else with the C oracle.  TEST/BENCH INFRASTRUCTURE -- never imported by boardlaw_amd."""
-import importlib.util
+"""CPU baseline driver (bench.py's cpu_baseline leg and nothing else): BASELINE config 2's search on the host cores of the
+box the bench runs on, with the C oracle's kernels (kind "port": oracle/liboracle*.so, bit-checked against the reference's
+CPU path by tests/test_oracle.py; nothing compiled from the reference's sources is used here).  SURVEY 8d:
+
+  (i)  as the reference runs it: one process, single-threaded native loops over the envs;
+  (ii) env-sharded over P processes = the physical cores, B/P envs each, sims/s summed (P and nproc stated);
+  and ns/descent (the reference's own unit, boardlaw/mcts/tests.py:163-182) for the -O2 build and for the -O0 build
+  (the reference's JIT loader passes no -O flag, boardlaw/cuda.py:29-45).
+
+TEST/BENCH INFRASTRUCTURE -- never imported by boardlaw_amd.  Workers are tests/cpu_worker.py (numpy + ctypes, no torch)."""
+import json
 import os
+import subprocess
+import sys
+import tempfile
 import time
 
 import numpy as np
-import torch
 
-import oracle_lib
-from oracle_lib import OracleSearch, f16_bits
-
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
 
 
-def _h(bits):
-    return torch.from_numpy(bits.view(np.int16)).view(torch.half)
-
-
-class RefKernels:
-    """oracle_lib.Oracle's numpy interface on top of the compiled reference modules (zero-copy tensor views)."""
-
-    def __init__(self):
-        def load(name):
-            spec = importlib.util.spec_from_file_location(name, os.path.join(ROOT, 'oracle', '_ref', name + '.so'))
-            m = importlib.util.module_from_spec(spec); spec.loader.exec_module(m)
-            return m
-        self.m, self.h = load('mctscuda'), load('hexcuda')
-
-    def _tree(self, logits, w, n, c_puct, seats, terminal, children):
-        return self.m.MCTS(_h(logits), _h(w), torch.from_numpy(n), _h(c_puct), torch.from_numpy(seats),
-                           torch.from_numpy(terminal).view(torch.bool), torch.from_numpy(children))
-
-    def descend(self, logits, w, n, c_puct, seats, terminal, children, rands=None, stats=None):
-        d = self.m.descend(self._tree(logits, w, n, c_puct, seats, terminal, children))   # draws its own rands (cpu.cpp:187)
-        return d.parents.numpy(), d.actions.numpy()
-
-    def root(self, *tree):
-        return self.m.root(self._tree(*tree)).view(torch.int16).numpy().view(np.uint16)
-
-    def backup(self, v, w, n, rewards, parents, terminal, leaves):
-        bk = self.m.Backup(v=_h(v), w=_h(w), n=torch.from_numpy(n), rewards=_h(rewards), parents=torch.from_numpy(parents),
-                           terminal=torch.from_numpy(terminal).view(torch.bool))
-        self.m.backup(bk, torch.from_numpy(leaves))
-
-    def hex_observe(self, board, seats):
-        return self.h.observe(torch.from_numpy(board), torch.from_numpy(seats)).numpy()
-
-    def hex_world_step(self, board, seats, actions):
-        nb = torch.from_numpy(board.copy())
-        rewards = self.h.step(nb, torch.from_numpy(seats), torch.from_numpy(actions)).numpy()
-        term = (rewards > 0).any(-1)
-        nb = nb.numpy(); nb[term] = 0
-        ns = np.where(term, 0, 1 - seats).astype(np.int32)
-        return nb, ns, rewards, term.astype(np.uint8)
-
-
-class _World:
-    pass
-
-
-def run_cpu_search(boardsize, nodes, width, depth, seconds_budget=25.0, envs=256):
-    from boardlaw_amd import networks, heads
-    threads = torch.get_num_threads()
-    torch.set_num_threads(1)
+def cgroup_cpu_limit():
+    """CPUs' worth of time this container may use (cgroup v2 cpu.max / v1 cfs quota), or None if unlimited."""
     try:
+        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()
+        return None if quota == 'max' else float(quota) / float(period)
+    except Exception:
+        pass
+    try:
+        quota = float(open('/sys/fs/cgroup/cpu/cpu.cfs_quota_us').read())
+        period = float(open('/sys/fs/cgroup/cpu/cpu.cfs_period_us').read())
+        return None if quota <= 0 else quota / period
+    except Exception:
+        return None
+
+
+def physical_cores():
+    """Cores this process can really run on at once: physical cores, capped by the affinity mask and the cgroup CPU quota
+    (a GPU-pool container sees the host's 256 hardware threads in nproc but is throttled to its quota)."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        import psutil
+        phys = psutil.cpu_count(logical=False)
+        if phys:
+            n = min(int(phys), n)
+    except Exception:
+        pass
+    limit = cgroup_cpu_limit()
+    if limit:
+        n = max(1, min(n, int(limit)))
+    return n
+
+
+def export_weights(path, boardsize, width, depth):
+    """FCModel default init under manual_seed(0), as bench.py builds it, in the worker's numpy layout."""
+    import torch
+    from boardlaw_amd import networks, heads
+    torch.manual_seed(0)
+    net = networks.FCModel(heads.Tensor((boardsize, boardsize, 2)), heads.Masked(boardsize ** 2), width=width, depth=depth)
+    blocks = list(net.body)
+    n = lambda t: t.detach().numpy().astype(np.float32)
+    np.savez(path, w0=n(blocks[0].weight), b0=n(blocks[0].bias), wb=np.stack([n(b.weight) for b in blocks[1:]]),
+             bb=np.stack([n(b.bias) for b in blocks[1:]]), alpha=np.array([float(getattr(b, 'α').detach()) for b in blocks[1:]], np.float32),
+             wp=n(net.policy.core.weight), bp=n(net.policy.core.bias), wv=n(net.value.core.weight), bv=n(net.value.core.bias))
+
+
+def launch(n, envs, seconds, weights, variant, boardsize, nodes, start_at):
+    env = {**os.environ, 'OMP_NUM_THREADS': '1', 'OPENBLAS_NUM_THREADS': '1', 'MKL_NUM_THREADS': '1'}
+    cmd = [sys.executable, os.path.join(HERE, 'cpu_worker.py'), '--boardsize', str(boardsize), '--nodes', str(nodes), '--envs', str(envs),
+           '--seconds', str(seconds), '--weights', weights, '--variant', variant, '--start-at', str(start_at)]
+    return [subprocess.Popen(cmd + ['--seed', str(i)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, text=True) for i in range(n)]
+
+
+def collect(procs, timeout):
+    out = []
+    for p in procs:
         try:
-            kern, kind = RefKernels(), 'reference'
-        except Exception:
-            kern, kind = oracle_lib.load(), 'port'
-        S, A = boardsize, boardsize * boardsize
-        torch.manual_seed(0)
-        net = networks.FCModel(heads.Tensor((S, S, 2)), heads.Masked(A), width=width, depth=depth)
-        rng = np.random.default_rng(0)
-        board = np.zeros((envs, S, S), np.uint8); seats = np.zeros(envs, np.int32)
-        for _ in range(A // 3):
-            valid = (kern.hex_observe(board, seats) == 0).all(-1).reshape(envs, -1)
-            board, seats, _, _ = kern.hex_world_step(board, seats, (rng.random(valid.shape) * valid).argmax(-1).astype(np.int32))
+            so, se = p.communicate(timeout=timeout)
+        except subprocess.TimeoutExpired:
+            p.kill(); so, se = p.communicate()
+        lines = [l for l in so.splitlines() if l.startswith('{')]
+        if p.returncode == 0 and lines:
+            out.append(json.loads(lines[-1]))
+    return out
 
-        def evaluate(b, s):
-            w = _World()
-            w.obs = torch.from_numpy(kern.hex_observe(b, s)); w.valid = (w.obs == 0).all(-1).reshape(len(b), -1)
-            w.seats = torch.from_numpy(s)
-            with torch.no_grad():
-                d = net(w)
-            return d.logits, d.v
 
-        def one_move(board, seats):
-            s = OracleSearch(kern, board, seats, nodes)
-            logits, v = evaluate(board, seats)
-            s.initialize(f16_bits(logits.numpy()), f16_bits(v.numpy()))
-            for _ in range(nodes - 1):
-                rands = f16_bits(rng.random((envs, nodes), dtype=np.float32))
-                parents, actions = s.descend(rands)
-                leaves, nb, ns = s.expand(parents, actions)
-                logits, v = evaluate(nb, ns)
-                s.finish(leaves, f16_bits(logits.numpy()), f16_bits(v.numpy()))
-            probs = oracle_lib.f16_vals(s.root_probs())
-            actions = (probs + rng.random(probs.shape) * 1e-3 * (probs > 0)).argmax(-1).astype(np.int32)
-            nb, ns, _, _ = kern.hex_world_step(board, seats, actions)
-            return nb, ns
-
-        moves, t0 = 0, time.perf_counter()
-        while True:
-            board, seats = one_move(board, seats)
-            moves += 1
-            el = time.perf_counter() - t0
-            if el > 0.6 * seconds_budget or el * (moves + 1) / moves > seconds_budget:
-                break
-        return {'value': envs * nodes * moves / el, 'unit': 'sims/s', 'cores': 1, 'kind': kind,
-                'sample': f'{moves} move(s) of {envs} envs x {nodes} sims, {boardsize}x{boardsize}, FCModel {width}x{depth} fp32, '
-                          f'1 thread, {"reference CPU sources built -O2 (oracle/_ref)" if kind == "reference" else "C oracle -O2"}; '
-                          f'{el:.1f}s'}
-    finally:
-        torch.set_num_threads(threads)
+def run_cpu_baseline(boardsize, nodes, width, depth, total_envs=4096, seconds_budget=24.0):
+    import oracle_lib
+    oracle_lib.load(''); oracle_lib.load('_O0')            # build the checker libraries before the workers race for them
+    P, nproc = physical_cores(), os.cpu_count()
+    with tempfile.TemporaryDirectory() as tmp:
+        weights = os.path.join(tmp, 'fcmodel.npz')
+        export_weights(weights, boardsize, width, depth)
+        t_par, t_one = 0.45 * seconds_budget, 0.15 * seconds_budget
+        envs = max(1, total_envs // P)
+        # (ii) all physical cores, started together
+        procs = launch(P, envs, t_par, weights, '', boardsize, nodes, time.time() + 3.0)
+        par = collect(procs, timeout=t_par * 4 + 60)
+        # (i) one process, and the -O0 build, side by side on two otherwise idle cores
+        procs = launch(1, 256, t_one, weights, '', boardsize, nodes, time.time() + 1.5) + \
+            launch(1, 256, t_one, weights, '_O0', boardsize, nodes, time.time() + 1.5)
+        one = collect(procs, timeout=t_one * 6 + 60)
+    if not par or len(one) < 2:
+        return {'value': None, 'unit': 'sims/s', 'cores': P, 'nproc': nproc, 'kind': 'port', 'sample': 'workers failed'}
+    rate = sum(r['sims'] / r['seconds'] for r in par)
+    ns = lambda r: 1e9 * r['descend_seconds'] / max(r['descents'], 1)
+    o2, o0 = one
+    return {
+        'value': rate, 'unit': 'sims/s', 'cores': len(par), 'nproc': nproc, 'kind': 'port',
+        'cgroup_cpu_limit': cgroup_cpu_limit(),
+        'sample': f'{len(par)} processes (one per usable physical core: min(physical cores, affinity, cgroup CPU quota); nproc {nproc}) x {envs} envs x {nodes} sims/move, {boardsize}x{boardsize}, '
+                  f'FCModel {width}x{depth} f32 (numpy, 1 BLAS thread each), C oracle -O2, {t_par:.0f} s each after a warm-up move '
+                  f'({sum(r["moves"] for r in par)} moves in total)',
+        'single_thread': {'value': o2['sims'] / o2['seconds'], 'unit': 'sims/s', 'envs': o2['envs'], 'ns_per_descent_O2': ns(o2),
+                          'ns_per_descent_O0': ns(o0), 'value_O0': o0['sims'] / o0['seconds'],
+                          'note': 'one process, 256 envs; -O0 = how the reference JIT-builds its sources (no -O flag, libm powf)'},
+        'ns_per_descent_parallel_O2': float(np.mean([ns(r) for r in par])),
+    }
