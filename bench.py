@@ -153,6 +153,7 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--plain-network', action='store_true', help='run the nn.Module under autocast instead of the fp16 inference plan')
     ap.add_argument('--torch-gemms', action='store_true', help='keep the Linears as torch (hipBLASLt) GEMMs instead of the fused MFMA kernel')
+    ap.add_argument('--timed-only', action='store_true', help='for profilers: only capture, warm-up and the timed moves; prints a reduced line')
     ap.add_argument('--no-reference-rng', action='store_true', help='skip the second timed region (torch rand_like per simulation)')
     ap.add_argument('--eager', action='store_true', help='launch kernel by kernel instead of replaying a HIP graph per move')
     args = ap.parse_args()
@@ -217,6 +218,13 @@ def main():
     sims_total = world * args.envs * NODES * args.steps
     value = sims_total / elapsed
 
+    if args.timed_only:
+        if rank == 0:
+            print(json.dumps({'metric': 'mcts_sims_per_sec', 'value': value, 'unit': 'sims/s', 'n_gpus': world, 'steps': args.steps,
+                              'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps, 'timed_only': True}))
+        if world > 1:
+            torch.distributed.destroy_process_group()
+        return
     value_torch_rng = None
     if world == 1 and not args.eager and not args.no_reference_rng:
         # the same moves with the reference's RNG protocol: one rand_like (B,T) f16 per simulation (cuda.cu:191) instead of

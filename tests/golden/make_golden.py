@@ -318,6 +318,84 @@ def gen_exp(out):
     print('expf table written')
 
 
+# --------------------------------------------------------------------------------------------------------------
+# 6. The rollout/trace API (boardlaw/analysis.py:47-87) with deterministic agents, and an agent checkpoint in the
+#    reference's wire format (mcts/__init__.py:231-241 inside pavlov/storage.py:52-56's torch.save)
+# --------------------------------------------------------------------------------------------------------------
+class EdgeAgent:
+    """Deterministic fixture agent: plays the k-th legal cell from the front (or back); also returns a float and an int
+    field so that combine_decisions' NaN / -1 blanks show up in the trace."""
+
+    def __init__(self, from_end, k=0):
+        self.from_end, self.k = from_end, k
+
+    def __call__(self, world, **kwargs):
+        from rebar import arrdict
+        valid = world.valid
+        order = valid.int().cumsum(-1) if not self.from_end else valid.int().flip(-1).cumsum(-1).flip(-1)
+        want = torch.minimum(torch.full_like(order[:, :1], self.k + 1), valid.sum(-1, keepdim=True))
+        actions = ((order == want) & valid).int().argmax(-1) if not self.from_end else \
+            (valid.shape[-1] - 1 - ((order == want) & valid).int().flip(-1).argmax(-1))
+        return arrdict.arrdict(actions=actions, v=world.seats.float() + .5, count=valid.sum(-1).int())
+
+
+def import_reference_analysis():
+    class Stub(types.ModuleType):
+        def __getattr__(self, k):
+            if k.startswith('__'):
+                raise AttributeError(k)
+            return Stub(self.__name__ + '.' + k)
+    for name in ('rebar.recording', 'pavlov.runs', 'pavlov.storage', 'boardlaw.arena'):     # imported, never used by rollout()
+        sys.modules[name] = Stub(name)
+    import pavlov, rebar, boardlaw
+    pavlov.runs, pavlov.storage = sys.modules['pavlov.runs'], sys.modules['pavlov.storage']
+    rebar.recording, boardlaw.arena = sys.modules['rebar.recording'], sys.modules['boardlaw.arena']
+    import boardlaw.analysis as analysis
+    return analysis
+
+
+def gen_rollout(hex_, out):
+    analysis = import_reference_analysis()
+    res = {}
+    # mixed starting positions and seats: env e has played e % 5 random legal moves
+    torch.manual_seed(77)
+    start = hex_.Hex.initial(12, 5, device='cpu')
+    for k in range(4):
+        actions = torch.distributions.Categorical(probs=start.valid.float()).sample()
+        stepped, _ = start.step(actions)
+        go = (torch.arange(12) % 5) > k
+        start[go] = stepped[go]
+    res['start_board'] = np_(start.board); res['start_seats'] = np_(start.seats)
+    for tag, kw in (('steps', dict(n_steps=45)), ('trajs', dict(n_trajs=9)), ('reps', dict(n_reps=2))):
+        worlds = start.clone()
+        trace = analysis.rollout(worlds, [EdgeAgent(False, 1), EdgeAgent(True, 0)], **kw)
+        res[tag + '_actions'] = np_(trace.actions); res[tag + '_board'] = np_(trace.worlds.board); res[tag + '_seats'] = np_(trace.worlds.seats)
+        res[tag + '_rewards'] = np_(trace.transitions.rewards); res[tag + '_terminal'] = np_(trace.transitions.terminal)
+        for a in ('0', '1'):
+            d = trace.decisions[a]
+            for k in ('actions', 'v', 'count', 'mask'):
+                res[f'{tag}_dec{a}_{k}'] = np_(d[k])
+    np.savez_compressed(os.path.join(out, 'rollout_5x5.npz'), **res)
+    print('rollout', {k: v.shape for k, v in res.items() if k.endswith('_actions')})
+
+
+def gen_snapshot(mcts_mod, hex_, networks, out):
+    torch.manual_seed(31)
+    worlds = hex_.Hex.initial(4, 5, device='cpu')
+    net = networks.FCModel(worlds.obs_space, worlds.action_space, width=16, depth=3)
+    with torch.no_grad():
+        for p in net.parameters():
+            if p.ndim == 0:
+                p.fill_(0.25)
+    agent = mcts_mod.MCTSAgent(net, n_nodes=16, c_puct=1 / 8)
+    opt = torch.optim.Adam(net.parameters(), lr=1e-3)
+    # what main.run's storer writes (boardlaw/main.py:155-160 -> pavlov/storage.py:29-39,52-56)
+    torch.save({'agent': agent.state_dict(), 'opt': opt.state_dict()}, os.path.join(out, 'snapshot_5x5.pt'))
+    d = net(worlds)
+    np.savez_compressed(os.path.join(out, 'snapshot_5x5_outputs.npz'), logits=np_(d.logits), v=np_(d.v))
+    print('snapshot', sorted(agent.state_dict())[:3], '...')
+
+
 if __name__ == '__main__':
     mcts_mod, hex_, networks, validation, mcuda, hcuda = import_reference()
     out = HERE if not VARIANT else os.path.join('/tmp', 'golden' + VARIANT)
@@ -326,6 +404,8 @@ if __name__ == '__main__':
     gen_search(mcts_mod, hex_, networks, mcuda, out)
     gen_toy(mcts_mod, validation, out)
     gen_exp(out)
+    gen_snapshot(mcts_mod, hex_, networks, out)
+    gen_rollout(hex_, out)
 
 
 # tests/golden/learning.npz: produced by calling the reference's boardlaw.learning.reward_to_go / present_value on seeded
