@@ -352,6 +352,7 @@ __global__ void __launch_bounds__(WAVES * 64) mlp_kernel(Params p, FinArgs f) {
         __syncthreads();
     }
     const uint16_t* Out = (const uint16_t*)(Part + htiles * 16 * 64);
+    CLK(34)
     if constexpr (!FINISH) {
         // coalesced stores: a wave writes one row's NH-1 policy outputs as consecutive halves
         for (int r = wave; r < 32; r += WAVES) {
@@ -410,6 +411,7 @@ __global__ void __launch_bounds__(WAVES * 64) mlp_kernel(Params p, FinArgs f) {
             vb0[e] = (mover == 0) ? tv : (uint16_t)(tv ^ 0x8000u); vb1[e] = (uint16_t)(vb0[e] ^ 0x8000u);
             if (fb[e] >= 0 && lane == 0) { f.v[(envbase[e] + leaf[e]) * 2] = vb0[e]; f.v[(envbase[e] + leaf[e]) * 2 + 1] = vb1[e]; }
         }
+        CLK(35)
         // the leaf's compacted policy row for the descents to come (bl_device.h: compact_store, same order and values):
         // the kept actions' pi = exp_table[logit bits] and (no child | action), squeezed in ascending action order
         if (f.cpi) {
@@ -432,6 +434,7 @@ __global__ void __launch_bounds__(WAVES * 64) mlp_kernel(Params p, FinArgs f) {
                 if (fb[e] >= 0 && lane == 0) f.nk[envbase[e] + leaf[e]] = (int16_t)(c0 + __builtin_popcountll(m1));
             }
         }
+        CLK(36)
         // backup (cuda.cu:205-236), leaf -> root: node j's value is v_j = (terminal_j ? 0 : v_{j+1}) + r_j with v_len the
         // leaf evaluation.  Every lane applies that step to its right neighbour's current value at once; after k rounds
         // the last k nodes of the path are final (each re-evaluation reads a final neighbour and recomputes the same
@@ -459,6 +462,7 @@ __global__ void __launch_bounds__(WAVES * 64) mlp_kernel(Params p, FinArgs f) {
             w0[e] = h2f(f2h(h2f((uint16_t)fw[e]) + h2f(f2h(x0[e]))));
             w1[e] = h2f(f2h(h2f((uint16_t)(fw[e] >> 16)) + h2f(f2h(x1[e]))));
         }
+        CLK(37)
         // stores, and the q range over all T slots of each env with the path's nodes replaced by their new statistics:
         // through this wave's LDS scratch (LDS operations of one wave execute in order)
         volatile uint32_t* vs = scr;
@@ -486,6 +490,7 @@ __global__ void __launch_bounds__(WAVES * 64) mlp_kernel(Params p, FinArgs f) {
                 nmin = max(nmin, max(~e0, ~e1)); vmax = max(vmax, max(e0, e1));
             }
         }
+        CLK(38)
         // max is associative: one reduction and one conditional atomic pair for the wave's four envs
         nmin = wave_max_u32(nmin); vmax = wave_max_u32(vmax);
         if (lane == 0 && fb[0] >= 0) {

@@ -24,3 +24,7 @@ for sim in range(1, 64):
         print(f'sim {sim:2d}: levels max {lv.max():.0f} p99 {np.percentile(lv,99):.0f}; iters max {it.max():.0f}')
         print('   mean env :', row(c.mean(0)))
         print('   worst env:', row(c[worst]))
+        tot = c[:, 8] + c[:, 9]
+        order = np.argsort(tot)
+        print('   total cycles per env (wave 0): p50 %.0f p90 %.0f p99 %.0f p99.9 %.0f max %.0f | slowest 5 envs: (levels, wave-0 evals, cycles) %s' % (
+            *np.percentile(tot, [50, 90, 99, 99.9]), tot.max(), [(int(lv[i]), int(c[i, 10]), int(tot[i])) for i in order[-5:]]))

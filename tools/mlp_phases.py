@@ -1,0 +1,38 @@
+"""Shader-clock phases of bl_sim_infer_finish (workgroup 0, thread 0) inside a real search: build the library with -DBL_MLP_CLK
+into tools/micro/libboardlaw_clk.so (tools/mlp_phases.py --build, where hipcc is), then run this on the GPU box."""
+import ctypes, os, subprocess, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB = os.path.join(ROOT, 'tools', 'micro', 'libboardlaw_clk.so')
+if '--build' in sys.argv:
+    sys.path.insert(0, ROOT)
+    from boardlaw_amd import build as b
+    subprocess.check_call([b.shutil.which('hipcc') or '/opt/rocm/bin/hipcc'] + b.FLAGS + ['-DBL_MLP_CLK'] + b.SOURCES + ['-o', LIB])
+    sys.exit(0)
+import numpy as np, torch
+sys.path.insert(0, ROOT)
+from boardlaw_amd import _native
+_native.LIBPATH = LIB
+from boardlaw_amd import networks
+from boardlaw_amd.hex import Hex
+from boardlaw_amd.mcts import MCTS, MoveRng
+from bench import premix
+gen = torch.Generator(device='cuda'); gen.manual_seed(0); torch.manual_seed(0)
+worlds = premix(Hex.initial(4096, 9), 27, gen)
+net = networks.Inference(networks.FCModel(worlds.obs_space, worlds.action_space, 512, 4).cuda(), fused=True)
+net.refresh()
+m = MCTS(worlds, n_nodes=64, rng=MoveRng(), obs_half=True)
+m.rng.start(63, m.decisions.logits[:, :, 0])
+m.initialize(net)
+names = {1: 'staged'}
+for l in range(5): names.update({2 + 3 * l: f'layer{l} gemm', 3 + 3 * l: f'layer{l} epilogue', 4 + 3 * l: f'layer{l} barrier'})
+names.update({34: 'heads gemm + staging', 35: 'softmax, logits/v stores', 36: 'compacted row', 37: 'backup scan', 38: 'w/n stores + q range', 40: 'atomics, end'})
+tot = {}
+for sim in range(1, 64):
+    m.simulate(net)
+    if sim in (5, 30, 60):
+        torch.cuda.synchronize()
+        clk = np.zeros(64, np.int64); _native.lib().bl_mlp_debug_clk(ctypes.c_void_p(clk.ctypes.data))
+        print(f'--- sim {sim}: workgroup 0 total {clk[40] - clk[0]} cycles')
+        prev = clk[0]
+        for i in sorted(names):
+            print(f'   {names[i]:26s} +{clk[i] - prev:7d}'); prev = clk[i]
