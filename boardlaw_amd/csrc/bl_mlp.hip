@@ -207,7 +207,9 @@ __global__ void __launch_bounds__(WAVES * 64) mlp_kernel(Params p, FinArgs f) {
                     st[i][k] = (w < wvalid && row0 + r < p.M) ? src[(long)(row0 + r) * wvalid + w] : 0u;
                 }
             }
+            CLK(50)
             gemm_prefetch<NT>(rg, p.w0, p.K0pad, wave * PASSES * NT, NT);
+            CLK(51)
 #pragma unroll
             for (int i = 0; i < RPT; i++) {
                 const int r = r_first + i * (NTHREADS / 32);
@@ -221,7 +223,9 @@ __global__ void __launch_bounds__(WAVES * 64) mlp_kernel(Params p, FinArgs f) {
                     dst[r * (ld >> 1) + w] = (w < wvalid && row0 + r < p.M) ? src[(long)(row0 + r) * wvalid + w] : 0u;
         }
     }
+    CLK(52)
     __syncthreads();
+    CLK(53)
     if constexpr (FINISH) {
 #pragma unroll
         for (int e = 0; e < EPW; e++) {
@@ -232,8 +236,13 @@ __global__ void __launch_bounds__(WAVES * 64) mlp_kernel(Params p, FinArgs f) {
             const int16_t* path = f.path + bb * (f.T + 2);
             flen[e] = path[0];
             fnode[e] = lane < f.T ? (int)path[1 + lane] : 0;
-            fvalid[e][0] = lane < f.A ? (int)f.valid[bb * f.A + lane] : 0;
-            fvalid[e][1] = lane + 64 < f.A ? (int)f.valid[bb * f.A + lane + 64] : 0;
+            // valid(a) = both observation planes of cell a empty (hex/__init__.py:154-159), read from the tile staged above
+            // (word a of a row = the two f16 planes of cell a; layer 1's epilogue is the first to overwrite this buffer).
+            // Loading f.valid here instead cost 4.5k cycles: the compiler tests the byte at once, and the s_waitcnt vmcnt(0)
+            // it needs for that also waits for the cold weight fragments requested just before.
+            const uint32_t* stg = (const uint32_t*)(R0 + 32 * ld * par0) + (EPW * wave + e) * (ld >> 1);
+            fvalid[e][0] = lane < f.A ? (int)(stg[lane] == 0u) : 0;
+            fvalid[e][1] = lane + 64 < f.A ? (int)(stg[lane + 64] == 0u) : 0;
         }
     }
     CLK(1)

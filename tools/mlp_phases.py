@@ -23,7 +23,7 @@ net.refresh()
 m = MCTS(worlds, n_nodes=64, rng=MoveRng(), obs_half=True)
 m.rng.start(63, m.decisions.logits[:, :, 0])
 m.initialize(net)
-names = {1: 'staged'}
+names = {50: 'obs loads issued', 51: 'weight prefetch issued', 52: 'obs in LDS', 53: 'staging barrier', 1: 'finish prefetch issued'}
 for l in range(5): names.update({2 + 3 * l: f'layer{l} gemm', 3 + 3 * l: f'layer{l} epilogue', 4 + 3 * l: f'layer{l} barrier'})
 names.update({34: 'heads gemm + staging', 35: 'softmax, logits/v stores', 36: 'compacted row', 37: 'backup scan', 38: 'w/n stores + q range', 40: 'atomics, end'})
 tot = {}
@@ -34,5 +34,5 @@ for sim in range(1, 64):
         clk = np.zeros(64, np.int64); _native.lib().bl_mlp_debug_clk(ctypes.c_void_p(clk.ctypes.data))
         print(f'--- sim {sim}: workgroup 0 total {clk[40] - clk[0]} cycles')
         prev = clk[0]
-        for i in sorted(names):
+        for i in [50, 51, 52, 53] + sorted(k for k in names if k < 50):
             print(f'   {names[i]:26s} +{clk[i] - prev:7d}'); prev = clk[i]
