@@ -101,7 +101,9 @@ __device__ __forceinline__ int bperm_i(int src_lane, int v) { return __builtin_a
 // the kernel is bound by the latency of its longest descent, not by VALU throughput.
 // ------------------------------------------------------------------------------------------------------------------
 template <int RMAX, int KT, bool FAST, bool COUNT, int NW>
-__global__ void __launch_bounds__(BL_WAVE * NW) sim_expand2_kernel(Search s, int sim, const uint16_t* rands, int16_t* leaves_out,
+// 8 waves per SIMD for boards up to 9x9: 4096 envs x 2 waves are the chip's 8192 wave slots, and without the bound the
+// kernel's 106 SGPRs admit 6 (a quarter of the envs would start only when others have finished)
+__global__ void __launch_bounds__(BL_WAVE * NW, (RMAX <= 3 ? 8 : 4)) sim_expand2_kernel(Search s, int sim, const uint16_t* rands, int16_t* leaves_out,
                                                                    void* obs_out, uint8_t* valid_out, int32_t* leaf_seats_out,
                                                                    unsigned long long* counters, int deep_thresh) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -149,6 +151,15 @@ __global__ void __launch_bounds__(BL_WAVE * NW) sim_expand2_kernel(Search s, int
     load_qrange(s.qrange + (long)BL_QWORDS * sim, lo, hi);
     const float rden = hi - lo + 1.e-4f;
     const float cpuct = h2f(s.c_puct[b]);
+    // transition_q (cuda.cu:101-105) of every node slot, both seats, once per launch: lane t normalises its own slot's
+    // w/(n + 1e-4); a level then fetches a child's q with one bpermute instead of dividing twice per level
+    uint32_t qp[KT];      // q[b,t,0] | q[b,t,1] << 16  (f16 bits)
+#pragma unroll
+    for (int kt = 0; kt < KT; kt++) {
+        const float den = (float)nn[kt] + 1.e-4f;
+        const float q0 = h2f((uint16_t)wp[kt]) / den, q1 = h2f((uint16_t)(wp[kt] >> 16)) / den;
+        qp[kt] = (uint32_t)f2h((q0 - lo) / rden) | ((uint32_t)f2h((q1 - lo) / rden) << 16);
+    }
 
     auto pick = [&](const int (&regs)[KT], int t) {       // regs[t], t wave-uniform
         int v = 0;
@@ -185,18 +196,14 @@ __global__ void __launch_bounds__(BL_WAVE * NW) sim_expand2_kernel(Search s, int
                 const int c = (int)(int16_t)(cc[r] >> 16);
                 const bool ex = c >= 0;
                 const int src = ex ? c : 0;
-                uint32_t w2 = 0; int nv = 0;
+                uint32_t q2 = 0; int nv = 0;
 #pragma unroll
                 for (int kt = 0; kt < KT; kt++) {
-                    const uint32_t a_ = (uint32_t)bperm_i(src & 63, (int)wp[kt]);
+                    const uint32_t a_ = (uint32_t)bperm_i(src & 63, (int)qp[kt]);
                     const int b_ = bperm_i(src & 63, nn[kt]);
-                    if ((src >> 6) == kt) { w2 = a_; nv = b_; }
+                    if ((src >> 6) == kt) { q2 = a_; nv = b_; }
                 }
-                if (ex) {
-                    const float wv = h2f((uint16_t)(seat ? (w2 >> 16) : w2));
-                    const float q32 = wv / ((float)nv + 1.e-4f);
-                    q[r] = h2f(f2h((q32 - lo) / rden));                  // transition_q, cuda.cu:101-105
-                }
+                if (ex) q[r] = h2f((uint16_t)(seat ? (q2 >> 16) : q2));
                 if (lowhalf && in[r]) { Nloc += ex ? nv : 1; nch += ex ? 1 : 0; }
             }
         }
