@@ -47,6 +47,7 @@ SYMBOLS = {
     'bl_sim_plant_root': (_i, [ctypes.POINTER(Search)] + [_vp] * 5 + [ctypes.c_float, _vp]),
     'bl_sim_init': (_i, [ctypes.POINTER(Search), _vp, _vp, _vp]),
     'bl_sim_compact': (_i, [ctypes.POINTER(Search), _vp, _vp]),
+    'bl_draw_actions': (_i, [_vp, _vp, _vp, _i, _i, _vp]),
     'bl_selftest': (_i, [_vp]),
     'bl_fold_variant': (_i, []),
 }

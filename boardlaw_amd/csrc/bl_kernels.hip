@@ -1050,6 +1050,31 @@ __global__ void __launch_bounds__(BL_WAVE) sim_n_leaves_kernel(const int16_t* pa
     if (lane == 0) out[b] = count;
 }
 
+// actions ~ Categorical(probs / sum(probs)) by inverse CDF, one uniform per env: the first action whose running total
+// (ascending a, f32) reaches u * total, among those with positive probability; the last such action if rounding leaves the
+// running total short.  One wave per env.
+__global__ void __launch_bounds__(BL_WAVE) draw_actions_kernel(const uint16_t* probs, const float* u, long long* actions, int A) {
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const uint16_t* p = probs + (long)b * A;
+    float carry = 0.f, total = 0.f;
+    for (int a0 = 0; a0 < A; a0 += BL_WAVE) total += (a0 + lane < A) ? h2f(p[a0 + lane]) : 0.f;
+    for (int m = 32; m > 0; m >>= 1) total += __shfl_xor(total, m, BL_WAVE);
+    const float target = u[b] * total;
+    int pick = -1, lastpos = -1;
+    for (int a0 = 0; a0 < A; a0 += BL_WAVE) {
+        const int a = a0 + lane;
+        const float v = a < A ? h2f(p[a]) : 0.f;
+        float x = v;
+        for (int d = 1; d < BL_WAVE; d <<= 1) { const float y = __shfl_up(x, d, BL_WAVE); if (lane >= d) x += y; }
+        x += carry;
+        const unsigned long long pos = __ballot(v > 0.f), hit = __ballot(v > 0.f && x >= target);
+        if (pick < 0 && hit) pick = a0 + __builtin_ctzll(hit);
+        if (pos) lastpos = a0 + 63 - __builtin_clzll(pos);
+        carry = __shfl(x, BL_WAVE - 1, BL_WAVE);
+    }
+    if (lane == 0) actions[b] = pick >= 0 ? pick : (lastpos >= 0 ? lastpos : 0);
+}
+
 __global__ void __launch_bounds__(256) zero_words_kernel(uint32_t* p, int n) {
     for (int i = threadIdx.x; i < n; i += blockDim.x) p[i] = 0;
 }
@@ -1398,6 +1423,12 @@ int bl_sim_root(const bl_search_t* s, int sim, void* probs, bl_stream_t stream) 
                                       (hipStream_t)stream, m, (uint16_t*)probs)
     BL_DISPATCH_GK(G, K, CALL)
 #undef CALL
+    return check_launch();
+}
+
+int bl_draw_actions(const void* probs, const float* uniforms, long long* actions, int B, int A, bl_stream_t stream) {
+    if (!probs || !uniforms || !actions || B <= 0 || A <= 0) return BL_EINVAL;
+    hipLaunchKernelGGL(draw_actions_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, (const uint16_t*)probs, uniforms, actions, A);
     return check_launch();
 }
 

@@ -61,6 +61,24 @@ class MoveRng(TorchRng):
         self.i += 1
         return r
 
+    # The two per-move draws, each as ONE launch of torch's generator plus the library (same distributions as the
+    # reference's calls, fewer kernels; TorchRng keeps torch.distributions for both):
+    def gamma(self, alpha, shape):
+        """Unnormalised Dirichlet draw: the Gamma(alpha, 1) variates torch's Dirichlet sampler starts from
+        (torch._sample_dirichlet = standard_gamma / sum).  bl_sim_plant_root normalises over the valid actions anyway
+        (mcts/__init__.py:19-22), so the intermediate normalisation over all actions is dropped."""
+        return torch._standard_gamma(alpha.expand(*shape, alpha.shape[-1]))
+
+    def draw_actions(self, probs):
+        """Categorical(probs / probs.sum()) by inverse CDF from one torch.rand per env (bl_draw_actions)."""
+        B, A = probs.shape
+        u = torch.rand((B,), dtype=torch.float, device=probs.device)
+        actions = torch.empty((B,), dtype=torch.long, device=probs.device)
+        with torch.cuda.device(probs.device):
+            _native.check(_native.lib().bl_draw_actions(probs.contiguous().data_ptr(), u.data_ptr(), actions.data_ptr(), B, A,
+                                                        _native.stream(probs.device)))
+        return actions
+
 
 def dirichlet_noise(logits, valid, eps, alpha_scale=10, rng=None):
     """mcts/__init__.py:13-24: mix a Dirichlet(alpha_scale/A) draw over the valid actions into the root prior."""
@@ -171,7 +189,10 @@ class MCTS:
             policy_raw, value_raw = policy_raw.float().contiguous(), value_raw.float().contiguous()
             valid = world.valid.contiguous()
             alpha = torch.full((self.n_actions,), self.alpha_scale / self.n_actions, dtype=torch.float, device=self.device)
-            draw = self.rng.dirichlet(alpha, (self.n_envs,)).float().contiguous()      # mcts/__init__.py:16-18
+            if hasattr(self.rng, 'gamma'):
+                draw = self.rng.gamma(alpha, (self.n_envs,)).float().contiguous()
+            else:
+                draw = self.rng.dirichlet(alpha, (self.n_envs,)).float().contiguous()  # mcts/__init__.py:16-18
             with torch.cuda.device(self.device):
                 _native.check(_native.lib().bl_sim_plant_root(ctypes.byref(self._search), policy_raw.data_ptr(), value_raw.data_ptr(),
                                                               valid.data_ptr(), world.seats.int().contiguous().data_ptr(),
@@ -295,6 +316,7 @@ class MCTS:
 
     def root(self):
         r = self.root_probs()
+        self._root_probs = r
         # the reference takes r.log() on the device and r.float().log().half() on the host (mcts/__init__.py:147);
         # here the host's values are looked up per f16 bit pattern so both paths agree bit for bit
         logits = _native.log_table(r.device)[r.view(torch.int16).long() & 0xffff]
@@ -370,7 +392,12 @@ class MCTSAgent:
     def _move(self, world, eval, kwargs, clone=True):
         m = mcts(world, self.network, **{**self.kwargs, **kwargs})
         r = m.root()
-        actions = r.logits.argmax(-1) if eval else m.rng.categorical(r.logits.float())
+        if eval:
+            actions = r.logits.argmax(-1)
+        elif hasattr(m.rng, 'draw_actions') and m.fused:
+            actions = m.rng.draw_actions(m._root_probs)
+        else:
+            actions = m.rng.categorical(r.logits.float())
         d = arrdict.arrdict(
             logits=r.logits,
             prior=r.prior,

@@ -207,6 +207,13 @@ int bl_sim_compact(const bl_search_t* s, const int16_t* leaves /*(B) or NULL*/, 
 int bl_selftest(bl_stream_t stream);
 int bl_fold_variant(void);   /* 1: one-wait-state fold in use; 0: ISA-padded fold */
 
+/* MCTSAgent's action draw (mcts/__init__.py:221: Categorical(logits = log of the root distribution).sample()) by inverse CDF:
+ * actions[b] = first action whose running total of probs[b,:] (f16, ascending, summed in f32) reaches uniforms[b] * total,
+ * among the actions with positive probability.  One launch instead of torch.multinomial's ~12; the caller supplies the
+ * uniforms (torch.rand from its generator).  Same distribution as the reference's draw, its own use of the generator. */
+int bl_draw_actions(const void* probs /*f16 (B,A)*/, const float* uniforms /*(B)*/, long long* actions_out /*i64 (B)*/,
+                    int B, int A, bl_stream_t stream);
+
 /* MCTS.n_leaves (mcts/__init__.py:151-152): per env, nodes with parents != -1 that no node names as its parent. */
 int bl_sim_n_leaves(const bl_search_t* s, long long* out /*i64 (B)*/, bl_stream_t stream);
 

@@ -898,3 +898,32 @@ def test_fold_wait_states_under_load():
     torch.cuda.synchronize()
     assert steps > 1e8
     assert L.bl_fold_variant() == (0 if os.environ.get('BL_FOLD_SAFE') else 1)
+
+
+@pytest.mark.parametrize('A,B', [(81, 4096), (9, 1000), (169, 512), (700, 64)])
+def test_draw_actions_is_an_inverse_cdf_sample(A, B):
+    """bl_draw_actions (MoveRng's action draw): the picked action has positive probability and brackets u * total in the
+    running sum (f64 on the host; 1e-5 of the total for the kernel's f32 summation order); the same row drawn 100k times
+    reproduces its probabilities within 5 sigma."""
+    from boardlaw_amd import _native
+    rng = np.random.default_rng(A)
+    p = rng.random((B, A)).astype(np.float32) ** 3 * (rng.random((B, A)) > .4)
+    p[:, 0] = np.maximum(p[:, 0], 1e-3) * (np.arange(B) % 2)          # rows whose first action is impossible
+    p[np.arange(B), rng.integers(0, A, B)] += .05
+    ph = torch.from_numpy(p).to(DEV).half()
+    u = torch.from_numpy(rng.random(B).astype(np.float32)).to(DEV)
+    actions = torch.empty(B, dtype=torch.long, device=DEV)
+    _native.check(_native.lib().bl_draw_actions(ph.data_ptr(), u.data_ptr(), actions.data_ptr(), B, A, _native.stream()))
+    pv, a = ph.float().cpu().numpy().astype(np.float64), actions.cpu().numpy()
+    cum = pv.cumsum(-1); total = cum[:, -1]; target = u.cpu().numpy().astype(np.float64) * total
+    rows = np.arange(B)
+    assert (pv[rows, a] > 0).all()
+    assert (cum[rows, a] >= target - 1e-5 * total).all() and (cum[rows, a] - pv[rows, a] <= target + 1e-5 * total).all()
+    n = 100_000
+    row = ph[:1].expand(n, A).contiguous()
+    un = torch.rand(n, device=DEV)
+    out = torch.empty(n, dtype=torch.long, device=DEV)
+    _native.check(_native.lib().bl_draw_actions(row.data_ptr(), un.data_ptr(), out.data_ptr(), n, A, _native.stream()))
+    freq = np.bincount(out.cpu().numpy(), minlength=A) / n
+    q = pv[0] / pv[0].sum()
+    assert (np.abs(freq - q) <= 5 * np.sqrt(q * (1 - q) / n) + 5 / n).all()      # 5 sigma, plus a few counts for the rare ones

@@ -1,14 +1,26 @@
-"""Per-move (not per-simulation) kernel time in a rocprofv3 --kernel-trace database of bench.py."""
+"""Per-move (not per-simulation) kernel time in a rocprofv3 --kernel-trace database of `bench.py --timed-only`: the trace is
+cut into moves at bl::sim_init_kernel (the first launch of every search); the last `moves` complete moves -- graph replays --
+are averaged.  Usage: python tools/per_move_kernels.py <db> <moves>"""
 import sqlite3, sys
-c = sqlite3.connect(sys.argv[1]); moves = float(sys.argv[2])
+from collections import defaultdict
+c = sqlite3.connect(sys.argv[1]); want = int(float(sys.argv[2]))
 cols = [r[1] for r in c.execute("pragma table_info(kernels)")]
 name = 'name' if 'name' in cols else 'kernel_name'
-rows = c.execute(f"select {name}, count(*), sum(end-start) from kernels group by {name} order by 3 desc").fetchall()
-tot = 0
-for n, k, t in rows:
-    if any(s in n for s in ('sim_expand', 'mlp_kernel', 'sim_finish')):
-        continue
-    tot += t
-    if t / moves > 3000:
-        print(f'{t/moves/1e3:8.1f} us/move  {k/moves:6.1f} calls/move  {n[:110]}')
-print(f'total non-simulation kernel time per move: {tot/moves/1e3:.1f} us')
+rows = c.execute(f"select {name}, start, end from kernels order by start").fetchall()
+cuts = [i for i, r in enumerate(rows) if 'sim_init_kernel' in r[0]]
+spans = list(zip(cuts[:-1], cuts[1:]))[-want:]
+tot, calls, wall, sims = defaultdict(float), defaultdict(float), 0.0, 0.0
+for a, b in spans:
+    wall += rows[b][1] - rows[a][1]
+    for n, s, e in rows[a:b]:
+        tot[n] += e - s; calls[n] += 1
+n_moves = len(spans)
+glue = 0.0
+print(f'{n_moves} moves, {wall / n_moves / 1e3:.1f} us from one search\'s first launch to the next')
+for n, t in sorted(tot.items(), key=lambda kv: -kv[1]):
+    sim = any(s in n for s in ('sim_expand', 'mlp_kernel', 'sim_finish'))
+    if not sim:
+        glue += t
+    if t / n_moves > 2500 or sim:
+        print(f'{t / n_moves / 1e3:8.1f} us/move  {calls[n] / n_moves:6.1f} calls/move  {"[simulation] " if sim else ""}{n[:100]}')
+print(f'kernel time per move outside the simulations: {glue / n_moves / 1e3:.1f} us in {sum(v for k, v in calls.items() if not any(s in k for s in ("sim_expand", "mlp_kernel", "sim_finish"))) / n_moves:.0f} launches')

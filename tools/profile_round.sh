@@ -10,7 +10,7 @@ db=$(find /tmp/rp_$tag -name "*.db" | head -1)
 echo "db: $db" >> $out/rocprof.err
 python $repo/tools/rocpd_stats.py $db $out/kernel_stats.csv > /dev/null
 # moves in the trace: the capture's eager warm-up run (1; the capture itself launches nothing) + warm-up replays + timed replays
-python $repo/tools/per_move_kernels.py $db $((steps + warm + 1)) > $out/per_move.txt 2>&1
+python $repo/tools/per_move_kernels.py $db $steps > $out/per_move.txt 2>&1
 python $repo/tools/gap_stats.py $db > $out/gaps.txt 2>&1
 head -14 $out/kernel_stats.csv
 cat $out/per_move.txt | tail -25
