@@ -478,7 +478,7 @@ __global__ void __launch_bounds__(BL_WAVE) descend_kernel(Tree m, const uint16_t
 
 // root_kernel, cuda.cu:107-118
 template <int G, int K>
-__global__ void __launch_bounds__(BL_WAVE) root_kernel(Tree m, uint16_t* probs) {
+__global__ void __launch_bounds__(BL_WAVE) root_kernel(Tree m, uint16_t* probs, const uint16_t* log_table, uint16_t* logits) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int grp = threadIdx.x / G, gl = threadIdx.x % G;
     const int b = blockIdx.x * (BL_WAVE / G) + grp;
@@ -498,7 +498,11 @@ __global__ void __launch_bounds__(BL_WAVE) root_kernel(Tree m, uint16_t* probs) 
 #pragma unroll
         for (int k = 0; k < K; k++) {
             const int a = k * G + gl;
-            if (a < m.A) probs[(long)b * m.A + a] = f2h(prob[k]);
+            if (a < m.A) {
+                const uint16_t pb = f2h(prob[k]);
+                probs[(long)b * m.A + a] = pb;
+                if (logits) logits[(long)b * m.A + a] = log_table[pb];       // MCTS.root's r.log() (mcts/__init__.py:147), per f16 bit pattern
+            }
         }
     }
 }
@@ -620,6 +624,23 @@ __global__ void __launch_bounds__(256) hex_observe_kernel(const uint8_t* board, 
         float2 o = make_float2(0.f, 0.f);
         if (color < 2) { if ((flip ? 1 - color : color) == 0) o.x = 1.f; else o.y = 1.f; }
         obs[idx] = o;
+    }
+}
+
+// observe + Hex.valid (hex/__init__.py:154-159: (obs == 0).all(-1)) in one pass
+__global__ void __launch_bounds__(256) hex_observe_valid_kernel(const uint8_t* board, const int32_t* seats, float2* obs, uint8_t* valid, long cells, int S) {
+    const int A = S * S;
+    const float invS = 1.0f / (float)S;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < cells; idx += (long)gridDim.x * blockDim.x) {
+        const long b = idx / A;
+        const int a = (int)(idx - b * A);
+        const int i = (int)(((float)a + 0.5f) * invS), j = a - i * S;
+        const bool flip = seats[b] == 1;
+        const int color = color_of(board[b * A + (flip ? j * S + i : a)]);
+        float2 o = make_float2(0.f, 0.f);
+        if (color < 2) { if ((flip ? 1 - color : color) == 0) o.x = 1.f; else o.y = 1.f; }
+        obs[idx] = o;
+        valid[idx] = color == 2;
     }
 }
 
@@ -1218,7 +1239,7 @@ int bl_mcts_root(const void* logits, const void* w, const int16_t* n, const void
     const int per = lds_bytes(A, false);
     const int blocks = (B + 64 / G - 1) / (64 / G);
 #define CALL(g, k) hipLaunchKernelGGL((root_kernel<g, k>), dim3(blocks), dim3(64), (size_t)per * (64 / g), \
-                                      (hipStream_t)stream, m, (uint16_t*)probs)
+                                      (hipStream_t)stream, m, (uint16_t*)probs, (const uint16_t*)nullptr, (uint16_t*)nullptr)
     BL_DISPATCH_GK(G, K, CALL)
 #undef CALL
     return check_launch();
@@ -1266,6 +1287,16 @@ int bl_hex_observe(const uint8_t* board, const int32_t* seats, float* obs, int B
     long blocks = (cells + 255) / 256; if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(hex_observe_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, board, seats,
                        (float2*)obs, cells, S);
+    return check_launch();
+}
+
+int bl_hex_observe_valid(const uint8_t* board, const int32_t* seats, float* obs, uint8_t* valid, int B, int S, bl_stream_t stream) {
+    if (!board || !seats || !obs || !valid || B <= 0 || S <= 0) return BL_EINVAL;
+    if (S > 32) return BL_ETOOBIG;
+    const long cells = (long)B * S * S;
+    long blocks = (cells + 255) / 256; if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(hex_observe_valid_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, board, seats,
+                       (float2*)obs, valid, cells, S);
     return check_launch();
 }
 
@@ -1409,10 +1440,10 @@ int bl_sim_plant_root(const bl_search_t* s, const float* policy_raw, const float
     return check_launch();
 }
 
-int bl_sim_root(const bl_search_t* s, int sim, void* probs, bl_stream_t stream) {
+int bl_sim_root(const bl_search_t* s, int sim, void* probs, const void* log_table, void* logits, bl_stream_t stream) {
     int rc = search_check(s);
     if (rc) return rc;
-    if (!probs || sim < 1 || sim > s->T) return BL_EINVAL;
+    if (!probs || sim < 1 || sim > s->T || (logits && !log_table)) return BL_EINVAL;
     const int A = s->boardsize * s->boardsize;
     Tree m{(const uint16_t*)s->logits, (const uint16_t*)s->w, s->n, (const uint16_t*)s->c_puct, s->seats, s->terminal,
            s->children, s->qrange + (long)BL_QWORDS * sim, s->exp_table, s->B, s->T, A, 2, 1};
@@ -1420,7 +1451,7 @@ int bl_sim_root(const bl_search_t* s, int sim, void* probs, bl_stream_t stream) 
     const int per = lds_bytes(A, false);
     const int blocks = (s->B + 64 / G - 1) / (64 / G);
 #define CALL(g, k) hipLaunchKernelGGL((root_kernel<g, k>), dim3(blocks), dim3(64), (size_t)per * (64 / g), \
-                                      (hipStream_t)stream, m, (uint16_t*)probs)
+                                      (hipStream_t)stream, m, (uint16_t*)probs, (const uint16_t*)log_table, (uint16_t*)logits)
     BL_DISPATCH_GK(G, K, CALL)
 #undef CALL
     return check_launch();

@@ -33,17 +33,27 @@ class Hex(arrdict.namedarrtuple('Hex', fields=('board', 'seats'))):
         self._obs = None
         self._valid = None
 
+    def _observe(self):
+        b, s = self.board, self.seats
+        if b.ndim == 3 and s.dtype == torch.int32 and b.dtype == torch.uint8 and b.is_contiguous() and s.is_contiguous() and b.is_cuda:
+            self._obs, self._valid = cuda.observe_valid(b, s)          # both in one launch
+        else:
+            self._obs = cuda.observe(b, s)
+
     @property
     def obs(self):
         if self._obs is None:
-            self._obs = cuda.observe(self.board, self.seats)
+            self._observe()
         return self._obs
 
     @property
     def valid(self):
         if self._valid is None:
-            lead = self.board.shape[:-2]
-            self._valid = (self.obs == 0).all(-1).reshape(*lead, -1)
+            if self._obs is None:
+                self._observe()
+            if self._valid is None:
+                lead = self.board.shape[:-2]
+                self._valid = (self.obs == 0).all(-1).reshape(*lead, -1)
         return self._valid
 
     def step(self, actions, reset=True, check=True):

@@ -62,3 +62,17 @@ def observe(board, seats):
             _native.check(_native.lib().bl_hex_observe(flat.data_ptr(), fseats.data_ptr(), obs.data_ptr(),
                                                        flat.shape[0], S, _native.stream(dev)))
     return obs.view(*board.shape, 2)
+
+
+def observe_valid(board, seats):
+    """board (B,S,S) u8, seats (B,) i32 -> (obs (B,S,S,2) f32, valid (B,S*S) bool) in one launch."""
+    _check(board, torch.uint8, 3, 'board'); _check(seats, torch.int32, 1, 'seats')
+    dev = _native.require_device(board, seats)
+    B, S, _ = board.shape
+    obs = torch.empty((B, S, S, 2), dtype=torch.float32, device=dev)
+    valid = torch.empty((B, S * S), dtype=torch.bool, device=dev)
+    if B:
+        with torch.cuda.device(dev):
+            _native.check(_native.lib().bl_hex_observe_valid(board.data_ptr(), seats.data_ptr(), obs.data_ptr(), valid.data_ptr(),
+                                                             B, S, _native.stream(dev)))
+    return obs, valid

@@ -128,7 +128,7 @@ class MCTS:
         if self.fused and not isinstance(world, hexmod.Hex):
             raise ValueError('The fused path is Hex-only')
         B, T, A, S, dev = self.n_envs, n_nodes, self.n_actions, self.n_seats, self.device
-        self.envs = torch.arange(B, device=dev)
+        self._envs = None
         self.sim = 0
         self.c_puct = torch.full((B,), c_puct, device=dev, dtype=torch.half)
         self._root_world = world
@@ -177,6 +177,12 @@ class MCTS:
             self.decisions = arrdict.arrdict(logits=f((B, T, A), np.nan, torch.half), v=f((B, T, S), np.nan, torch.half))
             self.stats = arrdict.arrdict(n=f((B, T), 0, torch.short), w=f((B, T, S), 0., torch.half))
             self.worlds[:, 0] = world
+
+    @property
+    def envs(self):
+        if self._envs is None:
+            self._envs = torch.arange(self.n_envs, device=self.device)
+        return self._envs
 
     # ------------------------------------------------------------------ mcts/__init__.py:72-80
     def initialize(self, network):
@@ -305,21 +311,27 @@ class MCTS:
         self.sim += 1
 
     # ------------------------------------------------------------------ mcts/__init__.py:142-152
-    def root_probs(self):
+    def root_probs(self, with_logits=False):
         if self.fused:
             probs = torch.empty((self.n_envs, self.n_actions), dtype=torch.half, device=self.device)
+            logits = torch.empty_like(probs) if with_logits else None
+            table = _native.log_table(self.device) if with_logits else None
             with torch.cuda.device(self.device):
                 _native.check(_native.lib().bl_sim_root(ctypes.byref(self._search), self.sim, probs.data_ptr(),
-                                                        _native.stream(self.device)))
-            return probs
-        return cuda.root(self._cuda())
+                                                        table.data_ptr() if with_logits else None,
+                                                        logits.data_ptr() if with_logits else None, _native.stream(self.device)))
+            return (probs, logits) if with_logits else probs
+        probs = cuda.root(self._cuda())
+        return (probs, None) if with_logits else probs
 
     def root(self):
-        r = self.root_probs()
+        r, logits = self.root_probs(with_logits=True)
         self._root_probs = r
         # the reference takes r.log() on the device and r.float().log().half() on the host (mcts/__init__.py:147);
-        # here the host's values are looked up per f16 bit pattern so both paths agree bit for bit
-        logits = _native.log_table(r.device)[r.view(torch.int16).long() & 0xffff]
+        # here the host's values are looked up per f16 bit pattern so both paths agree bit for bit (inside bl_sim_root on
+        # the fused path)
+        if logits is None:
+            logits = _native.log_table(r.device)[r.view(torch.int16).long() & 0xffff]
         return arrdict.arrdict(
             logits=logits,
             prior=self.decisions.logits[:, 0],
@@ -352,6 +364,19 @@ def mcts(worlds, network, **kwargs):
     for _ in range(m.n_nodes - 1):
         m.simulate(network)
     return m
+
+
+_constants = {}
+
+
+def _constant(n, value, device):
+    """(n,) i64 tensor filled with `value`, built once per (n, value, device): callers clone what they keep."""
+    key = (n, value, device.type, device.index)
+    if key not in _constants:
+        if device.type == 'cuda' and torch.cuda.is_current_stream_capturing():
+            return torch.full((n,), value, dtype=torch.long, device=device)
+        _constants[key] = torch.full((n,), value, dtype=torch.long, device=device)
+    return _constants[key]
 
 
 class MCTSAgent:
@@ -401,7 +426,7 @@ class MCTSAgent:
         d = arrdict.arrdict(
             logits=r.logits,
             prior=r.prior,
-            n_sims=torch.full_like(m.envs, m.sim + 1),     # the reference's off-by-one, kept
+            n_sims=_constant(m.n_envs, m.sim + 1, m.device),     # the reference's off-by-one, kept
             n_leaves=m.n_leaves(),
             v=r.v,
             actions=actions)
@@ -475,16 +500,25 @@ class _GraphedMove:
         B, A, T = world.n_envs, world.boardsize ** 2, int({**agent.kwargs}.get('n_nodes', 64))
         self.nbytes = B * T * (A * 13 + 2 * T + 64)
 
+    @staticmethod
+    def _clone_all(*trees):
+        """Fresh copies of every tensor of the given arrdicts with ONE multi-tensor copy launch (a .clone() per tensor is a
+        launch each: 10 per move)."""
+        leaves = [l for t in trees for l in arrdict.leaves(t)]
+        fresh = [torch.empty_like(l) for l in leaves]
+        torch._foreach_copy_(fresh, leaves)
+        it = iter(fresh)
+        return [t.map(lambda _: next(it)) for t in trees]
+
     def __call__(self, world):
-        self.board.copy_(world.board); self.seats.copy_(world.seats)
+        torch._foreach_copy_([self.board, self.seats], [world.board, world.seats])
         if hasattr(self.network, 'refresh_if_stale'):
             self.network.refresh_if_stale()    # in place, outside the graph: replays read the static f16 weight buffers
         self.graph.replay()
         if not self.step:
-            return self.out.clone()
-        d, w, t = self.out
-        w = w.clone()
-        return d.clone(), self.kind(board=w.board, seats=w.seats), t.clone()
+            return self._clone_all(self.out)[0]
+        d, w, t = self._clone_all(*self.out)
+        return d, self.kind(board=w.board, seats=w.seats), t
 
 
 class DummyAgent:

@@ -93,6 +93,10 @@ int bl_hex_world_step(const uint8_t* board_in, const int32_t* seats_in, const vo
  * Leading dims are flattened by the caller.  obs_out is fully written. */
 int bl_hex_observe(const uint8_t* board, const int32_t* seats, float* obs_out, int B, int boardsize, bl_stream_t stream);
 
+/* observe plus Hex.valid = (obs == 0).all(-1) (boardlaw/hex/__init__.py:148-159) in one launch; valid_out u8 (B, S*S). */
+int bl_hex_observe_valid(const uint8_t* board, const int32_t* seats, float* obs_out, uint8_t* valid_out, int B, int boardsize,
+                         bl_stream_t stream);
+
 /* ================= fused search step for Hex (no reference counterpart) ==================
  * One simulation of boardlaw/mcts/__init__.py:108-140 is  descend -> expand -> world.step -> observe -> network ->
  * store -> backup.  The reference runs ~25 torch ops and 4 host syncs around its three kernels; here everything
@@ -217,8 +221,11 @@ int bl_draw_actions(const void* probs /*f16 (B,A)*/, const float* uniforms /*(B)
 /* MCTS.n_leaves (mcts/__init__.py:151-152): per env, nodes with parents != -1 that no node names as its parent. */
 int bl_sim_n_leaves(const bl_search_t* s, long long* out /*i64 (B)*/, bl_stream_t stream);
 
-/* root distribution from qrange slot `sim` (call with sim = number of filled slots, i.e. MCTS.sim). */
-int bl_sim_root(const bl_search_t* s, int sim, void* probs_out /*f16 (B,A)*/, bl_stream_t stream);
+/* root distribution from qrange slot `sim` (call with sim = number of filled slots, i.e. MCTS.sim).  logits_out (f16 (B,A),
+ * may be NULL) = log_table[bits of probs_out]: MCTS.root's `r.log()` (mcts/__init__.py:147) through the caller's 65536-entry
+ * f16 -> f16 table (the host's r.float().log().half() for every bit pattern). */
+int bl_sim_root(const bl_search_t* s, int sim, void* probs_out /*f16 (B,A)*/, const void* log_table, void* logits_out,
+                bl_stream_t stream);
 
 /* MCTS.__init__ (mcts/__init__.py:43-67): children/parents/relation = -1, logits/v = NaN, w/n/rewards/terminal = 0,
  * every slot's board/seat = the root world's, qrange slots zeroed. */
