@@ -63,6 +63,25 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {      // row_shr 1
     v = max(v, (uint32_t)dpp_i<0x142, 0xa>(0, (int)v)); v = max(v, (uint32_t)dpp_i<0x143, 0xc>(0, (int)v));
     return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
 }
+// x[lane ^ off] for the softmax butterflies, off a power of two: DPP within a row (1, 2, 8), ds_swizzle within 32 lanes (4, 16),
+// v_permlane32_swap across the halves -- the same values __shfl_xor's ds_bpermute returns, without its address arithmetic and
+// LDS round trip (a butterfly of 6 steps over four envs: 1.5k -> 0.4k cycles)
+template <int OFF>
+__device__ __forceinline__ float xor_lane(float x) {
+    const int v = __builtin_bit_cast(int, x);
+    int r;
+    if constexpr (OFF == 1) r = __builtin_amdgcn_update_dpp(v, v, 0xB1, 0xf, 0xf, false);            // quad_perm [1,0,3,2]
+    else if constexpr (OFF == 2) r = __builtin_amdgcn_update_dpp(v, v, 0x4E, 0xf, 0xf, false);       // quad_perm [2,3,0,1]
+    else if constexpr (OFF == 4) r = __builtin_amdgcn_ds_swizzle(v, (4 << 10) | 0x1f);
+    else if constexpr (OFF == 8) r = __builtin_amdgcn_update_dpp(v, v, 0x128, 0xf, 0xf, false);      // row_ror:8
+    else if constexpr (OFF == 16) r = __builtin_amdgcn_ds_swizzle(v, (16 << 10) | 0x1f);
+    else {
+        const auto sw = __builtin_amdgcn_permlane32_swap((unsigned)v, (unsigned)v, false, false);   // {[lo,lo], [hi,hi]}
+        r = (int)((threadIdx.x & 32) ? sw[0] : sw[1]);
+    }
+    return __builtin_bit_cast(float, r);
+}
+
 __device__ __forceinline__ float dpp_next_lane(float beyond, float x) {   // lane j <- x[j + 1]; lane 63 <- `beyond`
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, beyond), __builtin_bit_cast(int, x), 0x130, 0xf, 0xf, false));
 }
@@ -392,23 +411,40 @@ __global__ void __launch_bounds__(WAVES * 64) mlp_kernel(Params p, FinArgs f) {
             }
             mx[e] = two ? ((ev[e][0] > ev[e][1]) ? ev[e][0] : ev[e][1]) : ev[e][0];
         }
-        for (int off = Wsm / 2; off > 0; off /= 2) {
-#pragma unroll
-            for (int e = 0; e < EPW; e++) { const float o = __shfl_xor(mx[e], off, 64); mx[e] = (mx[e] < o) ? o : mx[e]; }
-        }
+        CLK(54)
+#define BLM_MAXSTEP(OFF) if (Wsm > OFF) { _Pragma("unroll") for (int e = 0; e < EPW; e++) { const float o = xor_lane<OFF>(mx[e]); mx[e] = (mx[e] < o) ? o : mx[e]; } }
+        BLM_MAXSTEP(32) BLM_MAXSTEP(16) BLM_MAXSTEP(8) BLM_MAXSTEP(4) BLM_MAXSTEP(2) BLM_MAXSTEP(1)
+#undef BLM_MAXSTEP
+        CLK(55)
 #pragma unroll
         for (int e = 0; e < EPW; e++) { sum[e] = 0.f; sum[e] += expf(ev[e][0] - mx[e]); if (two) sum[e] += expf(ev[e][1] - mx[e]); }
-        for (int off = Wsm / 2; off > 0; off /= 2) {
-#pragma unroll
-            for (int e = 0; e < EPW; e++) sum[e] = sum[e] + __shfl_xor(sum[e], off, 64);
-        }
+        CLK(56)
+#define BLM_SUMSTEP(OFF) if (Wsm > OFF) { _Pragma("unroll") for (int e = 0; e < EPW; e++) sum[e] = sum[e] + xor_lane<OFF>(sum[e]); }
+        BLM_SUMSTEP(32) BLM_SUMSTEP(16) BLM_SUMSTEP(8) BLM_SUMSTEP(4) BLM_SUMSTEP(2) BLM_SUMSTEP(1)
+#undef BLM_SUMSTEP
+        CLK(57)
         uint16_t vb0[EPW], vb1[EPW];
         uint16_t lb[EPW][2];
 #pragma unroll
         for (int e = 0; e < EPW; e++) {
-            const int r = EPW * wave + e;
             const float lsum = logf(sum[e]);
             lb[e][0] = f2h(ev[e][0] - mx[e] - lsum); lb[e][1] = f2h(ev[e][1] - mx[e] - lsum);
+        }
+        // the leaf's compacted policy row (bl_device.h: compact_store): pi = exp_table[logit bits] of the kept actions.  The
+        // gathers go out FIRST -- ahead of the stores below, so that waiting for them later does not also wait for the
+        // stores' acknowledgements (vmcnt retires in order) -- and are consumed after the backup scan, which hides their trip.
+        CLK(58)
+        float pi[EPW][2];
+        bool in[EPW][2];
+#pragma unroll
+        for (int e = 0; e < EPW; e++) {
+            in[e][0] = f.cpi && fb[e] >= 0 && lane < Wsm && lane < A; in[e][1] = f.cpi && fb[e] >= 0 && two && lane < Wsm && lane + Wsm < A;
+            pi[e][0] = in[e][0] ? f.exp_table[lb[e][0]] : 0.f; pi[e][1] = in[e][1] ? f.exp_table[lb[e][1]] : 0.f;
+        }
+        CLK(59)
+#pragma unroll
+        for (int e = 0; e < EPW; e++) {
+            const int r = EPW * wave + e;
             if (fb[e] >= 0 && lane < Wsm) {
                 uint16_t* dst = f.logits + (envbase[e] + leaf[e]) * A;
                 if (lane < A) dst[lane] = lb[e][0];
@@ -421,28 +457,6 @@ __global__ void __launch_bounds__(WAVES * 64) mlp_kernel(Params p, FinArgs f) {
             if (fb[e] >= 0 && lane == 0) { f.v[(envbase[e] + leaf[e]) * 2] = vb0[e]; f.v[(envbase[e] + leaf[e]) * 2 + 1] = vb1[e]; }
         }
         CLK(35)
-        // the leaf's compacted policy row for the descents to come (bl_device.h: compact_store, same order and values):
-        // the kept actions' pi = exp_table[logit bits] and (no child | action), squeezed in ascending action order
-        if (f.cpi) {
-            float pi[EPW][2];
-            bool in[EPW][2];
-#pragma unroll
-            for (int e = 0; e < EPW; e++) {
-                in[e][0] = fb[e] >= 0 && lane < Wsm && lane < A; in[e][1] = fb[e] >= 0 && two && lane < Wsm && lane + Wsm < A;
-                pi[e][0] = in[e][0] ? f.exp_table[lb[e][0]] : 0.f; pi[e][1] = in[e][1] ? f.exp_table[lb[e][1]] : 0.f;
-            }
-#pragma unroll
-            for (int e = 0; e < EPW; e++) {
-                const long rowbase = (envbase[e] + leaf[e]) * A;
-                const bool k0 = in[e][0] && pi[e][0] != 0.f, k1 = in[e][1] && pi[e][1] != 0.f;
-                const unsigned long long m0 = __ballot(k0), m1 = __ballot(k1);
-                const unsigned long long below = (1ull << lane) - 1ull;
-                const int c0 = __builtin_popcountll(m0);
-                if (k0) { const int j = __builtin_popcountll(m0 & below); f.cpi[rowbase + j] = pi[e][0]; f.cca[rowbase + j] = 0xffff0000u | (uint32_t)lane; }
-                if (k1) { const int j = c0 + __builtin_popcountll(m1 & below); f.cpi[rowbase + j] = pi[e][1]; f.cca[rowbase + j] = 0xffff0000u | (uint32_t)(lane + Wsm); }
-                if (fb[e] >= 0 && lane == 0) f.nk[envbase[e] + leaf[e]] = (int16_t)(c0 + __builtin_popcountll(m1));
-            }
-        }
         CLK(36)
         // backup (cuda.cu:205-236), leaf -> root: node j's value is v_j = (terminal_j ? 0 : v_{j+1}) + r_j with v_len the
         // leaf evaluation.  Every lane applies that step to its right neighbour's current value at once; after k rounds
@@ -458,11 +472,31 @@ __global__ void __launch_bounds__(WAVES * 64) mlp_kernel(Params p, FinArgs f) {
             if (fb[e] < 0) flen[e] = 0;
             maxlen = flen[e] > maxlen ? flen[e] : maxlen;
         }
-        for (int k = 0; k < maxlen; k++) {
+        // In Hex a reward and `terminal` only ever sit on the LAST node of a path (a descent stops at a terminal node), so every
+        // interior node just passes its successor's value on, plus its own reward +0.0 (which turns a -0 into +0, once):
+        // v_j = v_leaf' + 0.0f for j < len - 1, v_leaf' = (terminal ? 0 : v) + r at the last node.  That is two instructions
+        // instead of `len` rounds (25 rounds on the deepest paths); the general scan remains for paths that do carry
+        // something on an interior node.
+        bool plain = true;
+#pragma unroll
+        for (int e = 0; e < EPW; e++) plain = plain && !__any(lane < flen[e] - 1 && (fterm[e] != 0 || frew[e] != 0u));
+        if (plain) {
 #pragma unroll
             for (int e = 0; e < EPW; e++) {
-                const float n0 = dpp_next_lane(h2f(vb0[e]), x0[e]), n1 = dpp_next_lane(h2f(vb1[e]), x1[e]);
-                if (lane < flen[e]) { x0[e] = (fterm[e] ? 0.f : n0) + r0[e]; x1[e] = (fterm[e] ? 0.f : n1) + r1[e]; }
+                if (flen[e] > 0) {
+                    const float l0 = (fterm[e] ? 0.f : h2f(vb0[e])) + r0[e], l1 = (fterm[e] ? 0.f : h2f(vb1[e])) + r1[e];   // right in lane len - 1
+                    const float b0 = readlane_f(l0, flen[e] - 1), b1 = readlane_f(l1, flen[e] - 1);
+                    if (lane < flen[e] - 1) { x0[e] = b0 + 0.f; x1[e] = b1 + 0.f; }
+                    else if (lane == flen[e] - 1) { x0[e] = b0; x1[e] = b1; }
+                }
+            }
+        } else {
+            for (int k = 0; k < maxlen; k++) {
+#pragma unroll
+                for (int e = 0; e < EPW; e++) {
+                    const float n0 = dpp_next_lane(h2f(vb0[e]), x0[e]), n1 = dpp_next_lane(h2f(vb1[e]), x1[e]);
+                    if (lane < flen[e]) { x0[e] = (fterm[e] ? 0.f : n0) + r0[e]; x1[e] = (fterm[e] ? 0.f : n1) + r1[e]; }
+                }
             }
         }
         float w0[EPW], w1[EPW];
@@ -470,6 +504,19 @@ __global__ void __launch_bounds__(WAVES * 64) mlp_kernel(Params p, FinArgs f) {
         for (int e = 0; e < EPW; e++) {
             w0[e] = h2f(f2h(h2f((uint16_t)fw[e]) + h2f(f2h(x0[e]))));
             w1[e] = h2f(f2h(h2f((uint16_t)(fw[e] >> 16)) + h2f(f2h(x1[e]))));
+        }
+        if (f.cpi) {
+#pragma unroll
+            for (int e = 0; e < EPW; e++) {
+                const long rowbase = (envbase[e] + leaf[e]) * A;
+                const bool k0 = in[e][0] && pi[e][0] != 0.f, k1 = in[e][1] && pi[e][1] != 0.f;
+                const unsigned long long m0 = __ballot(k0), m1 = __ballot(k1);
+                const unsigned long long below = (1ull << lane) - 1ull;
+                const int c0 = __builtin_popcountll(m0);
+                if (k0) { const int j = __builtin_popcountll(m0 & below); f.cpi[rowbase + j] = pi[e][0]; f.cca[rowbase + j] = 0xffff0000u | (uint32_t)lane; }
+                if (k1) { const int j = c0 + __builtin_popcountll(m1 & below); f.cpi[rowbase + j] = pi[e][1]; f.cca[rowbase + j] = 0xffff0000u | (uint32_t)(lane + Wsm); }
+                if (fb[e] >= 0 && lane == 0) f.nk[envbase[e] + leaf[e]] = (int16_t)(c0 + __builtin_popcountll(m1));
+            }
         }
         CLK(37)
         // stores, and the q range over all T slots of each env with the path's nodes replaced by their new statistics:

@@ -25,7 +25,7 @@ m.rng.start(63, m.decisions.logits[:, :, 0])
 m.initialize(net)
 names = {50: 'obs loads issued', 51: 'weight prefetch issued', 52: 'obs in LDS', 53: 'staging barrier', 1: 'finish prefetch issued'}
 for l in range(5): names.update({2 + 3 * l: f'layer{l} gemm', 3 + 3 * l: f'layer{l} epilogue', 4 + 3 * l: f'layer{l} barrier'})
-names.update({34: 'heads gemm + staging', 35: 'softmax, logits/v stores', 36: 'compacted row', 37: 'backup scan', 38: 'w/n stores + q range', 40: 'atomics, end'})
+names.update({34: 'heads gemm + staging', 35: 'logits/v stores, tanh', 36: 'compacted row', 37: 'backup scan', 38: 'w/n stores + q range', 40: 'atomics, end'})
 tot = {}
 for sim in range(1, 64):
     m.simulate(net)
@@ -34,5 +34,7 @@ for sim in range(1, 64):
         clk = np.zeros(64, np.int64); _native.lib().bl_mlp_debug_clk(ctypes.c_void_p(clk.ctypes.data))
         print(f'--- sim {sim}: workgroup 0 total {clk[40] - clk[0]} cycles')
         prev = clk[0]
-        for i in [50, 51, 52, 53] + sorted(k for k in names if k < 50):
+        names.update({54: 'Out -> regs, masks', 55: 'max butterfly', 56: 'exp', 57: 'sum butterfly', 58: 'log, logit bits', 59: 'exp-table gathers issued'})
+        order = [50, 51, 52, 53] + sorted(k for k in names if k < 35) + [54, 55, 56, 57, 58, 59] + sorted(k for k in names if 35 <= k < 50)
+        for i in order:
             print(f'   {names[i]:26s} +{clk[i] - prev:7d}'); prev = clk[i]
