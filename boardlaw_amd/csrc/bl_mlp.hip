@@ -82,6 +82,12 @@ __device__ __forceinline__ float xor_lane(float x) {
     return __builtin_bit_cast(float, r);
 }
 
+__device__ __forceinline__ uint32_t wave_or_u32(uint32_t v) {       // as wave_max_u32, with OR
+    v |= (uint32_t)dpp_i<0x111, 0xf>(0, (int)v); v |= (uint32_t)dpp_i<0x112, 0xf>(0, (int)v);
+    v |= (uint32_t)dpp_i<0x114, 0xf>(0, (int)v); v |= (uint32_t)dpp_i<0x118, 0xf>(0, (int)v);
+    v |= (uint32_t)dpp_i<0x142, 0xa>(0, (int)v); v |= (uint32_t)dpp_i<0x143, 0xc>(0, (int)v);
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
 __device__ __forceinline__ float dpp_next_lane(float beyond, float x) {   // lane j <- x[j + 1]; lane 63 <- `beyond`
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, beyond), __builtin_bit_cast(int, x), 0x130, 0xf, 0xf, false));
 }
@@ -519,31 +525,35 @@ __global__ void __launch_bounds__(WAVES * 64) mlp_kernel(Params p, FinArgs f) {
             }
         }
         CLK(37)
-        // stores, and the q range over all T slots of each env with the path's nodes replaced by their new statistics:
-        // through this wave's LDS scratch (LDS operations of one wave execute in order)
-        volatile uint32_t* vs = scr;
+        // stores, and the q range over all T slots of each env with the path's nodes replaced by their new statistics.  Lane t
+        // still holds slot t's old (w, n) and lane j the j-th path node's new ones: a slot's old q counts unless the slot is on
+        // the path (a 64-bit mask, OR-reduced over the lanes with DPP), a path node's new q always does.  No LDS involved.
         uint32_t wnew[EPW]; int nnew[EPW];
+        uint32_t nmin = 0, vmax = 0;
 #pragma unroll
         for (int e = 0; e < EPW; e++) {
             wnew[e] = (uint32_t)f2h(w0[e]) | ((uint32_t)f2h(w1[e]) << 16);
             nnew[e] = (int)(int16_t)(fn[e] + 2);                            // n += 1 once per seat (cuda.cu:230), int16 wrap kept
-            if (lane < flen[e]) {
+            const bool onp = lane < flen[e];
+            if (onp) {
                 const long i = envbase[e] + fnode[e];
                 *(uint32_t*)(f.w + i * 2) = wnew[e];
                 f.n[i] = (int16_t)nnew[e];
             }
-            if (lane < T) { vs[e * 128 + lane] = fallW[e]; vs[e * 128 + 64 + lane] = (uint32_t)fallN[e]; }
-        }
-#pragma unroll
-        for (int e = 0; e < EPW; e++) if (lane < flen[e]) { vs[e * 128 + fnode[e]] = wnew[e]; vs[e * 128 + 64 + fnode[e]] = (uint32_t)nnew[e]; }
-        uint32_t nmin = 0, vmax = 0;
-#pragma unroll
-        for (int e = 0; e < EPW; e++) {
-            if (fb[e] >= 0 && lane < T) {
-                const uint32_t ww = vs[e * 128 + lane];
-                const float den = (float)(int)(int16_t)vs[e * 128 + 64 + lane] + 1.e-4f;
-                const uint32_t e0 = enc(h2f((uint16_t)ww) / den), e1 = enc(h2f((uint16_t)(ww >> 16)) / den);
-                nmin = max(nmin, max(~e0, ~e1)); vmax = max(vmax, max(e0, e1));
+            const uint32_t lo = (onp && fnode[e] < 32) ? (1u << fnode[e]) : 0u, hi = (onp && fnode[e] >= 32) ? (1u << (fnode[e] - 32)) : 0u;
+            const uint32_t mlo = wave_or_u32(lo), mhi = wave_or_u32(hi);
+            const bool replaced = ((lane < 32 ? mlo >> lane : mhi >> (lane - 32)) & 1u) != 0;
+            if (fb[e] >= 0) {
+                if (lane < T && !replaced) {
+                    const float den = (float)fallN[e] + 1.e-4f;
+                    const uint32_t e0 = enc(h2f((uint16_t)fallW[e]) / den), e1 = enc(h2f((uint16_t)(fallW[e] >> 16)) / den);
+                    nmin = max(nmin, max(~e0, ~e1)); vmax = max(vmax, max(e0, e1));
+                }
+                if (onp) {
+                    const float den = (float)nnew[e] + 1.e-4f;
+                    const uint32_t e0 = enc(w0[e] / den), e1 = enc(w1[e] / den);
+                    nmin = max(nmin, max(~e0, ~e1)); vmax = max(vmax, max(e0, e1));
+                }
             }
         }
         CLK(38)
