@@ -2,6 +2,7 @@
 
 There is deliberately NO fallback: if the library is missing or a call fails this raises, so a GPU run can never
 silently go through PyTorch or the CPU."""
+import contextlib
 import ctypes
 import os
 
@@ -49,6 +50,7 @@ SYMBOLS = {
     'bl_sim_init': (_i, [ctypes.POINTER(Search), _vp, _vp, _vp]),
     'bl_sim_compact': (_i, [ctypes.POINTER(Search), _vp, _vp]),
     'bl_draw_actions': (_i, [_vp, _vp, _vp, _i, _i, _vp]),
+    'bl_copy_many': (_i, [_vp, _i, _vp]),
     'bl_selftest': (_i, [_vp]),
     'bl_fold_variant': (_i, []),
 }
@@ -88,6 +90,54 @@ def check(rc):
 
 def stream(device=None):
     return torch.cuda.current_stream(device).cuda_stream
+
+
+class Copy(ctypes.Structure):
+    """bl_copy_t"""
+    _fields_ = [('src', _vp), ('dst', _vp)] + [(k, ctypes.c_ulonglong) for k in ('row_bytes', 'rows', 'src_pitch', 'dst_pitch')]
+
+
+COPY_MAX = 24
+
+
+def clone_many(tensors):
+    """Fresh contiguous copies of device tensors with one bl_copy_many launch per COPY_MAX of them (a .clone() each is a
+    launch each).  Handles contiguous tensors and views whose rows along dim 0 are contiguous (tree[:, 0] slices); anything
+    else is copied by torch."""
+    fresh = [torch.empty(t.shape, dtype=t.dtype, device=t.device) for t in tensors]
+    items, dev = [], None
+    for src, dst in zip(tensors, fresh):
+        size = src.element_size()
+        if src.numel() == 0:
+            continue
+        if not src.is_cuda or (dev is not None and src.device != dev):
+            dst.copy_(src)
+        elif src.is_contiguous():
+            items.append(Copy(src.data_ptr(), dst.data_ptr(), src.numel() * size, 1, 0, 0)); dev = src.device
+        elif src.dim() >= 1 and src[0].is_contiguous() and src.stride(0) >= src[0].numel():
+            row = src[0].numel() * size
+            items.append(Copy(src.data_ptr(), dst.data_ptr(), row, src.shape[0], src.stride(0) * size, row)); dev = src.device
+        else:
+            dst.copy_(src)
+    with torch.cuda.device(dev) if dev is not None else contextlib.nullcontext():
+        for i in range(0, len(items), COPY_MAX):
+            chunk = items[i:i + COPY_MAX]
+            check(lib().bl_copy_many((Copy * len(chunk))(*chunk), len(chunk), stream(dev)))
+    return fresh
+
+
+def copy_many(dsts, srcs):
+    """dst.copy_(src) for same-shape, same-dtype contiguous device tensors, one launch."""
+    items = []
+    for dst, src in zip(dsts, srcs):
+        if not (dst.is_contiguous() and src.is_contiguous() and dst.dtype == src.dtype and dst.shape == src.shape and dst.device == src.device and src.is_cuda):
+            raise NativeError('copy_many wants contiguous device tensors of equal shape and dtype')
+        items.append(Copy(src.data_ptr(), dst.data_ptr(), src.numel() * src.element_size(), 1, 0, 0))
+    if items:
+        with torch.cuda.device(dsts[0].device):
+            for i in range(0, len(items), COPY_MAX):
+                chunk = items[i:i + COPY_MAX]
+                check(lib().bl_copy_many((Copy * len(chunk))(*chunk), len(chunk), stream(dsts[0].device)))
 
 
 def ptr(t):

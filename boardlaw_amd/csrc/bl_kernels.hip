@@ -1074,6 +1074,29 @@ __global__ void __launch_bounds__(BL_WAVE) sim_n_leaves_kernel(const int16_t* pa
 // actions ~ Categorical(probs / sum(probs)) by inverse CDF, one uniform per env: the first action whose running total
 // (ascending a, f32) reaches u * total, among those with positive probability; the last such action if rounding leaves the
 // running total short.  One wave per env.
+// Up to BL_COPY_MAX device-to-device copies as one launch: blockIdx.y = the copy (rows x row_bytes, each end with its own
+// pitch), its blocks stride over 16-byte words when both ends and pitches allow it, else over 2-byte or 1-byte units.
+struct CopyBatch { bl_copy_t it[BL_COPY_MAX]; };
+template <typename U>
+__device__ __forceinline__ void copy_units(const bl_copy_t& c, size_t tid, size_t nth) {
+    const size_t w = c.row_bytes / sizeof(U), total = w * c.rows;
+    const uint8_t* src = (const uint8_t*)c.src; uint8_t* dst = (uint8_t*)c.dst;
+    if (c.rows == 1) { for (size_t i = tid; i < w; i += nth) ((U*)dst)[i] = ((const U*)src)[i]; return; }
+    for (size_t i = tid; i < total; i += nth) {
+        const size_t r = i / w, k = i - r * w;
+        ((U*)(dst + r * c.dst_pitch))[k] = ((const U*)(src + r * c.src_pitch))[k];
+    }
+}
+__global__ void __launch_bounds__(256) copy_many_kernel(CopyBatch cb) {
+    const bl_copy_t& c = cb.it[blockIdx.y];
+    const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x, nth = (size_t)gridDim.x * blockDim.x;
+    const unsigned long long bits = (unsigned long long)(uintptr_t)c.src | (unsigned long long)(uintptr_t)c.dst | c.row_bytes |
+                                    (c.rows > 1 ? (c.src_pitch | c.dst_pitch) : 0ull);
+    if ((bits & 15) == 0) copy_units<uint4>(c, tid, nth);
+    else if ((bits & 1) == 0) copy_units<uint16_t>(c, tid, nth);
+    else copy_units<uint8_t>(c, tid, nth);
+}
+
 __global__ void __launch_bounds__(BL_WAVE) draw_actions_kernel(const uint16_t* probs, const float* u, long long* actions, int A) {
     const int b = blockIdx.x, lane = threadIdx.x;
     const uint16_t* p = probs + (long)b * A;
@@ -1460,6 +1483,25 @@ int bl_sim_root(const bl_search_t* s, int sim, void* probs, const void* log_tabl
 int bl_draw_actions(const void* probs, const float* uniforms, long long* actions, int B, int A, bl_stream_t stream) {
     if (!probs || !uniforms || !actions || B <= 0 || A <= 0) return BL_EINVAL;
     hipLaunchKernelGGL(draw_actions_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, (const uint16_t*)probs, uniforms, actions, A);
+    return check_launch();
+}
+
+int bl_copy_many(const bl_copy_t* items, int n, bl_stream_t stream) {
+    if (n < 0 || n > BL_COPY_MAX || (n > 0 && !items)) return BL_EINVAL;
+    CopyBatch c{};
+    unsigned long long most = 0;
+    for (int k = 0; k < n; k++) {
+        const unsigned long long bytes = items[k].row_bytes * items[k].rows;
+        if (bytes && (!items[k].src || !items[k].dst)) return BL_EINVAL;
+        if (items[k].rows > 1 && (items[k].src_pitch < items[k].row_bytes || items[k].dst_pitch < items[k].row_bytes)) return BL_EINVAL;
+        c.it[k] = items[k];
+        if (bytes > most) most = bytes;
+    }
+    if (most == 0) return BL_OK;
+    unsigned long long blocks = (most / 16 + 255) / 256;           // one 16-byte word per thread of the largest copy ...
+    if (blocks < 1) blocks = 1;
+    if (blocks > 128) blocks = 128;                                 // ... up to 128 blocks per copy, then strided
+    hipLaunchKernelGGL(copy_many_kernel, dim3((unsigned)blocks, n), dim3(256), 0, (hipStream_t)stream, c);
     return check_launch();
 }
 

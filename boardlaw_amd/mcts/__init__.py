@@ -130,7 +130,7 @@ class MCTS:
         B, T, A, S, dev = self.n_envs, n_nodes, self.n_actions, self.n_seats, self.device
         self._envs = None
         self.sim = 0
-        self.c_puct = torch.full((B,), c_puct, device=dev, dtype=torch.half)
+        self.c_puct = torch.full((B,), c_puct, device=dev, dtype=torch.half)      # per-env and writable: not a shared constant
         self._root_world = world
 
         if self.fused:
@@ -194,7 +194,7 @@ class MCTS:
             policy_raw, value_raw = network.root_raw(world)
             policy_raw, value_raw = policy_raw.float().contiguous(), value_raw.float().contiguous()
             valid = world.valid.contiguous()
-            alpha = torch.full((self.n_actions,), self.alpha_scale / self.n_actions, dtype=torch.float, device=self.device)
+            alpha = _constant(self.n_actions, self.alpha_scale / self.n_actions, self.device, torch.float)
             if hasattr(self.rng, 'gamma'):
                 draw = self.rng.gamma(alpha, (self.n_envs,)).float().contiguous()
             else:
@@ -369,13 +369,14 @@ def mcts(worlds, network, **kwargs):
 _constants = {}
 
 
-def _constant(n, value, device):
-    """(n,) i64 tensor filled with `value`, built once per (n, value, device): callers clone what they keep."""
-    key = (n, value, device.type, device.index)
+def _constant(n, value, device, dtype=torch.long):
+    """(n,) tensor filled with `value`, built once per (n, value, dtype, device) and shared: read-only by convention
+    (callers clone what they hand out).  Saves a fill launch per use inside every move."""
+    key = (n, value, dtype, device.type, device.index)
     if key not in _constants:
         if device.type == 'cuda' and torch.cuda.is_current_stream_capturing():
-            return torch.full((n,), value, dtype=torch.long, device=device)
-        _constants[key] = torch.full((n,), value, dtype=torch.long, device=device)
+            return torch.full((n,), value, dtype=dtype, device=device)
+        _constants[key] = torch.full((n,), value, dtype=dtype, device=device)
     return _constants[key]
 
 
@@ -502,16 +503,18 @@ class _GraphedMove:
 
     @staticmethod
     def _clone_all(*trees):
-        """Fresh copies of every tensor of the given arrdicts with ONE multi-tensor copy launch (a .clone() per tensor is a
-        launch each: 10 per move)."""
+        """Fresh copies of every tensor of the given arrdicts with ONE launch (bl_copy_many; a .clone() per tensor is a
+        launch each: ten per move)."""
         leaves = [l for t in trees for l in arrdict.leaves(t)]
-        fresh = [torch.empty_like(l) for l in leaves]
-        torch._foreach_copy_(fresh, leaves)
-        it = iter(fresh)
+        it = iter(_native.clone_many(leaves))
         return [t.map(lambda _: next(it)) for t in trees]
 
     def __call__(self, world):
-        torch._foreach_copy_([self.board, self.seats], [world.board, world.seats])
+        if (world.board.dtype == self.board.dtype and world.seats.dtype == self.seats.dtype and world.board.is_contiguous()
+                and world.seats.is_contiguous()):
+            _native.copy_many([self.board, self.seats], [world.board, world.seats])
+        else:
+            self.board.copy_(world.board); self.seats.copy_(world.seats)
         if hasattr(self.network, 'refresh_if_stale'):
             self.network.refresh_if_stale()    # in place, outside the graph: replays read the static f16 weight buffers
         self.graph.replay()

@@ -70,6 +70,7 @@ class Inference:
         self.fused = fused
         self._static = None
         self._packed = None
+        self._root_heads = None
         self._stamped = None
 
     def __call__(self, worlds):
@@ -146,14 +147,26 @@ class Inference:
                 stageh[:A] = w[-4]; stageh[A] = w[-2][0]
                 pk['wh'].view(-1).copy_(pack_fragment_major(stageh).view(-1))
                 pk['bh'][:A].copy_(w[-3]); pk['bh'][A].copy_(w[-1][0])
+            m = self.model
+            if type(m.policy).__name__ in ('MaskedOutput', 'DiscreteOutput') and m.value.core.weight.shape[0] == 1:
+                if self._root_heads is None or self._root_heads[0].device != m.policy.core.weight.device:
+                    A, W = m.policy.core.weight.shape
+                    dev = m.policy.core.weight.device
+                    self._root_heads = (torch.empty((A + 1, W), dtype=torch.float, device=dev), torch.empty((A + 1,), dtype=torch.float, device=dev))
+                wcat, bcat = self._root_heads
+                A = wcat.shape[0] - 1
+                wcat[:A].copy_(m.policy.core.weight); wcat[A:].copy_(m.value.core.weight)
+                bcat[:A].copy_(m.policy.core.bias); bcat[A:].copy_(m.value.core.bias)
         self._stamped = self._stamp()
 
     def root_raw(self, worlds):
         """fp32 pre-head outputs for the root evaluation (MCTS.initialize runs the network outside autocast,
         mcts/__init__.py:72-76): the module's own fp32 parameters and torch's GEMMs, with each block's alpha*y, x + .
         and the next relu issued as one kernel (bl_rezero_relu_f32; same two roundings as torch's mul and add).
-        Bit-identical to FCModel.raw in fp32 (tests/test_gpu_parity.py::test_root_plan_matches_module)."""
+        The body and the policy head are bit-identical to FCModel.raw in fp32; the value head, computed by the stacked heads'
+        GEMM instead of a one-column GEMM of its own, within 1e-6 (tests/test_gpu_parity.py::test_root_plan_matches_module)."""
         from . import _native
+        self.refresh_if_stale()
         m = self.model
         blocks = list(m.body)
         obs = worlds.obs
@@ -168,6 +181,11 @@ class Inference:
                 _native.check(L.bl_rezero_relu_f32(x.data_ptr(), y.data_ptr(), getattr(blk, 'α').data_ptr(), x_new.data_ptr(),
                                                    r.data_ptr(), x.numel(), st))
                 x = x_new
+            # both heads' Linears as one GEMM over the stacked (A+1, W) weights (refresh() keeps the stack current): the
+            # value head alone, one output column, is a 17 us launch of its own plus torch's bias broadcast
+            if self._root_heads is not None:
+                out = F.linear(x, *self._root_heads)
+                return out[:, :-1], out[:, -1]
             return F.linear(x, m.policy.core.weight, m.policy.core.bias), F.linear(x, m.value.core.weight, m.value.core.bias).squeeze(-1)
 
     def fused_params(self):

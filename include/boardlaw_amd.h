@@ -218,6 +218,17 @@ int bl_fold_variant(void);   /* 1: one-wait-state fold in use; 0: ISA-padded fol
 int bl_draw_actions(const void* probs /*f16 (B,A)*/, const float* uniforms /*(B)*/, long long* actions_out /*i64 (B)*/,
                     int B, int A, bl_stream_t stream);
 
+/* Up to BL_COPY_MAX device-to-device copies in ONE launch (`items` is HOST memory, read before the call returns).  Copy k
+ * moves `rows` rows of `row_bytes` bytes; row r starts at src + r*src_pitch and dst + r*dst_pitch (rows == 1: a flat copy,
+ * pitches ignored).  What replaces the reference's `decisions.clone()` / `arrdict.clone()` (mcts/__init__.py:229,
+ * rebar/arrdict.py) -- a launch per tensor, ten per move -- when a captured move's outputs are handed to the caller. */
+#define BL_COPY_MAX 24
+typedef struct {
+    const void* src; void* dst;
+    unsigned long long row_bytes, rows, src_pitch, dst_pitch;
+} bl_copy_t;
+int bl_copy_many(const bl_copy_t* items, int n, bl_stream_t stream);
+
 /* MCTS.n_leaves (mcts/__init__.py:151-152): per env, nodes with parents != -1 that no node names as its parent. */
 int bl_sim_n_leaves(const bl_search_t* s, long long* out /*i64 (B)*/, bl_stream_t stream);
 

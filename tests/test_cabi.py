@@ -40,20 +40,24 @@ def test_argument_validation_without_gpu():
     assert b'limits' in L.bl_strerror(-2)
 
 
-def test_search_struct_layout_matches_the_header(tmp_path):
-    """bl_search_t as gcc lays it out from include/boardlaw_amd.h == the ctypes mirror, field by field."""
+@pytest.mark.parametrize('ctype,mirror', [('bl_search_t', 'Search'), ('bl_copy_t', 'Copy')])
+def test_struct_layout_matches_the_header(tmp_path, ctype, mirror):
+    """The header's structs as gcc lays them out from include/boardlaw_amd.h == their ctypes mirrors, field by field."""
     import subprocess
     from boardlaw_amd import _native
-    names = [f[0] for f in _native.Search._fields_]
+    cls = getattr(_native, mirror)
+    names = [f[0] for f in cls._fields_]
     src = tmp_path / 'layout.c'
     src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "boardlaw_amd.h"\nint main(void) {\n'
-                   + ''.join(f'printf("{n} %zu\\n", offsetof(bl_search_t, {n}));\n' for n in names)
-                   + 'printf("sizeof %zu\\n", sizeof(bl_search_t)); return 0; }\n')
+                   + ''.join(f'printf("{n} %zu\\n", offsetof({ctype}, {n}));\n' for n in names)
+                   + f'printf("sizeof %zu\\n", sizeof({ctype})); return 0; }}\n')
     exe = tmp_path / 'layout'
     subprocess.check_call(['gcc', '-I', os.path.join(ROOT, 'include'), str(src), '-o', str(exe)])
     got = dict(l.split() for l in subprocess.check_output([str(exe)]).decode().splitlines())
-    assert int(got.pop('sizeof')) == ctypes.sizeof(_native.Search)
-    assert {k: int(v) for k, v in got.items()} == {n: getattr(_native.Search, n).offset for n in names}
+    assert int(got.pop('sizeof')) == ctypes.sizeof(cls)
+    assert {k: int(v) for k, v in got.items()} == {n: getattr(cls, n).offset for n in names}
+    if mirror == 'Copy':
+        assert _native.COPY_MAX == int(re.search(r'#define BL_COPY_MAX (\d+)', open(os.path.join(ROOT, 'include', 'boardlaw_amd.h')).read()).group(1))
 
 
 def test_exp_table_is_host_libm(oracle):

@@ -1,6 +1,7 @@
 """Per-move (not per-simulation) kernel time in a rocprofv3 --kernel-trace database of `bench.py --timed-only`: the trace is
 cut into moves at bl::sim_init_kernel (the first launch of every search); the last `moves` complete moves -- graph replays --
-are averaged.  Usage: python tools/per_move_kernels.py <db> <moves>"""
+are averaged.  Usage: python tools/per_move_kernels.py <db> <moves> [--sequence]   (--sequence: also the last move's launches outside the
+simulations, in order)"""
 import sqlite3, sys
 from collections import defaultdict
 c = sqlite3.connect(sys.argv[1]); want = int(float(sys.argv[2]))
@@ -24,3 +25,9 @@ for n, t in sorted(tot.items(), key=lambda kv: -kv[1]):
     if t / n_moves > 2500 or sim:
         print(f'{t / n_moves / 1e3:8.1f} us/move  {calls[n] / n_moves:6.1f} calls/move  {"[simulation] " if sim else ""}{n[:100]}')
 print(f'kernel time per move outside the simulations: {glue / n_moves / 1e3:.1f} us in {sum(v for k, v in calls.items() if not any(s in k for s in ("sim_expand", "mlp_kernel", "sim_finish"))) / n_moves:.0f} launches')
+if '--sequence' in sys.argv:
+    a, b = spans[-1]
+    print('last move, launches outside the simulations in order (start relative to the move, duration):')
+    for n, s_, e in rows[a:b]:
+        if not any(x in n for x in ('sim_expand', 'mlp_kernel', 'sim_finish')):
+            print(f'  +{(s_ - rows[a][1]) / 1e3:9.1f} us {(e - s_) / 1e3:7.1f} us  {n[:150]}')
