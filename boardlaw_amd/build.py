@@ -7,7 +7,7 @@ import subprocess
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
-SOURCES = [os.path.join(HERE, 'csrc', f) for f in ('bl_kernels.hip', 'bl_expand.hip', 'bl_mlp.hip')]
+SOURCES = [os.path.join(HERE, 'csrc', f) for f in ('bl_kernels.hip', 'bl_expand.hip', 'bl_mlp.hip', 'bl_root.hip')]
 HEADERS = [os.path.join(ROOT, 'include', 'boardlaw_amd.h'), os.path.join(HERE, 'csrc', 'bl_device.h')]
 LIB = os.path.join(HERE, 'libboardlaw_amd.so')
 

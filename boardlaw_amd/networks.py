@@ -50,6 +50,13 @@ def pack_fragment_major(m):
     return m.view(N // 32, 32, K // 64, 2, 4, 8).permute(0, 2, 4, 3, 1, 5).contiguous()
 
 
+def pack_fragment_major_f32(m):
+    """(N, K) f32 -> the layout bl_root_mlp_f32 streams: [N/16][K/16][lane=64][4] with lane = 16*(k-quarter) + (n % 16);
+    N % 16 == 0, K % 16 == 0."""
+    N, K = m.shape
+    return m.view(N // 16, 16, K // 16, 4, 4).permute(0, 2, 3, 1, 4).contiguous()
+
+
 class Inference:
     """fp16 inference plan for an FCModel inside the search: the same arithmetic as the module under fp16 autocast
     (what the reference runs in MCTS.simulate), issued as 6 GEMMs + 5 elementwise launches instead of ~45:
@@ -61,6 +68,7 @@ class Inference:
     raw() are bit-identical to FCModel.raw under autocast (tests/test_gpu_parity.py::test_inference_plan_matches_autocast)."""
 
     wants_half_obs = True
+    ROOT_FUSED_MIN_ROWS = 2048
 
     def __init__(self, model, fused=False):
         """fused=True additionally runs all Linears as ONE MFMA kernel (bl_mlp_forward_f16) when the width is a multiple
@@ -71,6 +79,7 @@ class Inference:
         self._static = None
         self._packed = None
         self._root_heads = None
+        self._root_packed = None
         self._stamped = None
 
     def __call__(self, worlds):
@@ -103,6 +112,16 @@ class Inference:
         buf, staging = 32 * (W + 8) * 2, (NHpad // 32) * 4096 + 32 * NHpad * 2     # bl_mlp_forward_f16's LDS budget
         return (W in (128, 256, 512, 768, 1024) and -(-K0 // 64) * 64 <= W and buf + max(buf, staging) <= 160 * 1024
                 and type(m.policy).__name__ in ('MaskedOutput', 'DiscreteOutput') and blocks[0].weight.is_cuda)
+
+    def _root_fusable(self):
+        """bl_root_mlp_f32's limits: fp32 parameters on the GPU, width a multiple of 128 up to 1024, the flattened
+        observation no wider than the body."""
+        m = self.model
+        blocks = list(m.body)
+        W, K0 = blocks[0].weight.shape
+        return (W % 128 == 0 and 128 <= W <= 1024 and -(-K0 // 64) * 64 <= W and blocks[0].weight.dtype == torch.float
+                and type(m.policy).__name__ in ('MaskedOutput', 'DiscreteOutput') and m.value.core.weight.shape[0] == 1
+                and blocks[0].weight.is_cuda)
 
     def _stamp(self):
         srcs, alphas = self._sources()
@@ -157,6 +176,29 @@ class Inference:
                 A = wcat.shape[0] - 1
                 wcat[:A].copy_(m.policy.core.weight); wcat[A:].copy_(m.value.core.weight)
                 bcat[:A].copy_(m.policy.core.bias); bcat[A:].copy_(m.value.core.bias)
+            if self.fused and self._root_fusable():
+                # layout of bl_root_mlp_f32: fp32, zero-padded intake, stacked blocks, policy+value head stacked
+                srcs32 = srcs
+                W, K0 = srcs32[0].shape
+                D, A = len(alphas), srcs32[-4].shape[0]
+                K0pad, NHpad = -(-K0 // 64) * 64, -(-(A + 1) // 16) * 16
+                dev = srcs32[0].device
+                if self._root_packed is None or self._root_packed['w0'].device != dev:
+                    z = lambda *s: torch.zeros(s, dtype=torch.float, device=dev)
+                    self._root_packed = dict(w0=z(W, K0pad), b0=z(W), wb=z(max(D, 1), W, W), bb=z(max(D, 1), W), al=z(max(D, 1)),
+                                             wh=z(NHpad, W), bh=z(NHpad), dims=(W, K0, K0pad, D, A + 1, NHpad))
+                rp = self._root_packed
+                stage0 = torch.zeros((W, K0pad), dtype=torch.float, device=dev); stage0[:, :K0] = srcs32[0]
+                rp['w0'].view(-1).copy_(pack_fragment_major_f32(stage0).view(-1)); rp['b0'].copy_(srcs32[1])
+                for d in range(D):
+                    rp['wb'][d].view(-1).copy_(pack_fragment_major_f32(srcs32[2 + 2 * d].detach().float()).view(-1))
+                    rp['bb'][d].copy_(srcs32[3 + 2 * d]); rp['al'][d].copy_(alphas[d])
+                stageh = torch.zeros((NHpad, W), dtype=torch.float, device=dev)
+                stageh[:A] = srcs32[-4]; stageh[A] = srcs32[-2][0]
+                rp['wh'].view(-1).copy_(pack_fragment_major_f32(stageh).view(-1))
+                rp['bh'][:A].copy_(srcs32[-3]); rp['bh'][A].copy_(srcs32[-1][0])
+            else:
+                self._root_packed = None
         self._stamped = self._stamp()
 
     def root_raw(self, worlds):
@@ -172,6 +214,19 @@ class Inference:
         obs = worlds.obs
         x0 = obs.reshape(obs.shape[0], -1).float().contiguous()
         L, st = _native.lib(), _native.stream(x0.device)
+        # bl_root_mlp_f32 takes 16 rows per workgroup through all layers: it beats the library GEMMs once the batch fills
+        # at least half of the 256 CUs (102 vs 135 us at 4096 rows of 512x4; 64 workgroups of 1024x8 are 3x slower)
+        if self.fused and self._root_packed is not None and x0.is_cuda and x0.shape[0] >= self.ROOT_FUSED_MIN_ROWS:
+            rp = self._root_packed
+            W, K0, K0pad, D, NH, NHpad = rp['dims']
+            M = x0.shape[0]
+            policy = torch.empty((M, NH - 1), dtype=torch.float, device=x0.device)
+            value = torch.empty((M,), dtype=torch.float, device=x0.device)
+            with torch.cuda.device(x0.device):
+                _native.check(L.bl_root_mlp_f32(x0.data_ptr(), M, K0, rp['w0'].data_ptr(), rp['b0'].data_ptr(), rp['wb'].data_ptr(),
+                                                rp['bb'].data_ptr(), rp['al'].data_ptr(), rp['wh'].data_ptr(), rp['bh'].data_ptr(),
+                                                W, D, K0pad, NH, NHpad, policy.data_ptr(), value.data_ptr(), st))
+            return policy, value
         with torch.no_grad():
             x = F.linear(x0, blocks[0].weight, blocks[0].bias)
             r = F.relu(x)

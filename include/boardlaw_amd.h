@@ -177,6 +177,19 @@ int bl_mlp_forward_f16(const void* obs /*f16 (M,K0)*/, int M, int K0, const void
                        const void* bb, const float* alphas /*(D) f32*/, const void* wh, const void* bh, int W, int D,
                        int K0pad, int NH, int NHpad, void* policy_out, void* value_out, bl_stream_t stream);
 
+/* The ROOT evaluation's Linears in fp32 (MCTS.initialize calls the network outside autocast, mcts/__init__.py:72-76;
+ * networks.py:10-40) as one kernel on v_mfma_f32_16x16x4_f32: intake, D ReZero blocks, policy+value head Linears, with
+ * torch's fp32 rounding points (bias add, alpha*y, x + ., relu); the heads' nonlinearities are bl_sim_plant_root's.
+ * Matrices are f32 (out, in) -- w0 (W,K0pad) zero-padded from (W,K0); wb (D,W,W); wh (NHpad,W) with rows 0..NH-2 the policy
+ * Linear, row NH-1 the value Linear, zero rows after -- each PACKED fragment-major:
+ *     packed[n/16][k/16][lane][s] = M[16*(n/16) + (lane&15)][16*(k/16) + 4*(lane>>4) + s],  lane < 64, s < 4
+ * (boardlaw_amd/networks.py: pack_fragment_major_f32).  W % 128 == 0, W <= 1024, K0pad % 64 == 0, K0pad <= W,
+ * NHpad % 16 == 0; BL_ETOOBIG otherwise.  Writes policy_out (M,NH-1) f32 and value_out (M) f32; GEMM summation order is
+ * the kernel's own (agrees with the module's library GEMMs to fp32 rounding). */
+int bl_root_mlp_f32(const float* obs /*(M,K0)*/, int M, int K0, const float* w0, const float* b0, const float* wb,
+                    const float* bb, const float* alphas /*(D)*/, const float* wh, const float* bh, int W, int D, int K0pad,
+                    int NH, int NHpad, float* policy_out, float* value_out, bl_stream_t stream);
+
 /* bl_mlp_forward_f16 followed by bl_sim_finish as ONE launch: the workgroup that took 32 leaves through the network also
  * applies the heads to them, stores logits/v, backs up along the recorded paths and publishes the next q range; what
  * that step reads from the tree is requested at the start of the kernel and arrives under the GEMMs.  Same results as
