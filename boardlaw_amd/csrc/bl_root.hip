@@ -9,8 +9,11 @@
 // differs from the library GEMM's, so outputs agree with the module to fp32 rounding (~1e-6 relative;
 // tests/test_gpu_parity.py::test_root_plan_matches_module).  The heads' nonlinearities stay in bl_sim_plant_root.
 //
-// MFMA bound: 16 rows x 512 x 512 x 2 flop per layer and workgroup at 256 flop/clk/CU = 32.8 k cycles; 256 workgroups (4096
-// rows) fill the chip's 256 CUs; weights (1 MiB per layer per workgroup) need half of a CU's L1 fill rate.
+// Bounds at 4096 rows of 512x4 (256 workgroups, one per CU): 9.6 GFLOP at the measured 146 TFLOP/s of
+// v_mfma_f32_16x16x4_f32 (tools/micro/mfma_f32_rate.hip: 32 cycles per instruction and SIMD) = 66 us -- 77 us with the
+// weight loads compiled out; 256 workgroups x 4.5 MiB of weights through the L2 = 1.15 GB -- 79 us with the MFMAs compiled
+// out (14.6 TB/s of L2 reads, what this access pattern gets); both together 102 us (the two streams do not overlap
+// perfectly), against 135 us for the library plan.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "../../include/boardlaw_amd.h"
@@ -54,13 +57,16 @@ __device__ __forceinline__ void gemm(const float* in, int ld, const float* Wp, i
 #pragma unroll
     for (int d = 0; d < DEPTH; d++) { load(wq[d], d); __builtin_amdgcn_sched_barrier(0); }   // K % 64 == 0: whole rounds only
     const float* xrow = in + n * ld + 4 * g;
+    float4v xb = *(const float4v*)xrow;
     auto compute = [&](float4v (&slot)[NT], int kb) {
-        const float4v xb = *(const float4v*)(xrow + 16 * kb);
+        // the next block's activations are requested before this block's MFMAs: their LDS round trip runs under them
+        const float4v xn = *(const float4v*)(xrow + 16 * (kb + 1 < KB ? kb + 1 : kb));
 #pragma unroll
         for (int s = 0; s < 4; s++) {
 #pragma unroll
             for (int t = 0; t < NT; t++) if (t < ntiles) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(slot[t][s], xb[s], acc[t], 0, 0, 0);
         }
+        xb = xn;
     };
     // A slot is refilled only after its MFMAs are issued (no register copies): DEPTH - 1 blocks stay in flight.  No
     // conditionals inside a round, and the refills pinned in place (the scheduler otherwise sinks a round's loads to its end
