@@ -19,15 +19,15 @@ n_moves = len(spans)
 glue = 0.0
 print(f'{n_moves} moves, {wall / n_moves / 1e3:.1f} us from one search\'s first launch to the next')
 for n, t in sorted(tot.items(), key=lambda kv: -kv[1]):
-    sim = any(s in n for s in ('sim_expand', 'mlp_kernel', 'sim_finish'))
+    sim = any(s in n for s in ('sim_expand', 'blmlp::mlp_kernel', 'sim_finish'))
     if not sim:
         glue += t
     if t / n_moves > 2500 or sim:
         print(f'{t / n_moves / 1e3:8.1f} us/move  {calls[n] / n_moves:6.1f} calls/move  {"[simulation] " if sim else ""}{n[:100]}')
-print(f'kernel time per move outside the simulations: {glue / n_moves / 1e3:.1f} us in {sum(v for k, v in calls.items() if not any(s in k for s in ("sim_expand", "mlp_kernel", "sim_finish"))) / n_moves:.0f} launches')
+print(f'kernel time per move outside the simulations: {glue / n_moves / 1e3:.1f} us in {sum(v for k, v in calls.items() if not any(s in k for s in ("sim_expand", "blmlp::mlp_kernel", "sim_finish"))) / n_moves:.0f} launches')
 if '--sequence' in sys.argv:
     a, b = spans[-1]
     print('last move, launches outside the simulations in order (start relative to the move, duration):')
     for n, s_, e in rows[a:b]:
-        if not any(x in n for x in ('sim_expand', 'mlp_kernel', 'sim_finish')):
+        if not any(x in n for x in ('sim_expand', 'blmlp::mlp_kernel', 'sim_finish')):
             print(f'  +{(s_ - rows[a][1]) / 1e3:9.1f} us {(e - s_) / 1e3:7.1f} us  {n[:150]}')
