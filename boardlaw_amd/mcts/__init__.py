@@ -22,6 +22,7 @@ import torch
 import torch.distributions
 
 from .. import _native, arrdict
+from .. import profiling
 from . import cuda
 
 
@@ -185,6 +186,7 @@ class MCTS:
         return self._envs
 
     # ------------------------------------------------------------------ mcts/__init__.py:72-80
+    @profiling.roctx
     def initialize(self, network):
         world = self._root_world if self.fused else self.worlds[:, 0]
         if (self.fused and self.fuse_finish and hasattr(network, 'root_raw') and world.board.is_cuda
@@ -225,11 +227,13 @@ class MCTS:
         return cuda.mcts(self.decisions.logits, self.stats.w, self.stats.n, self.c_puct, self.worlds.seats,
                          self.transitions.terminal, self.tree.children)
 
+    @profiling.roctx
     def descend(self):
         m = self._cuda()
         result = cuda.descend(m, self.rng.rand_like(m.logits[:, :, 0]))
         return result.parents.long(), result.actions.long()
 
+    @profiling.roctx
     def backup(self, leaves):
         bk = cuda.Backup(v=self.decisions.v, w=self.stats.w, n=self.stats.n, rewards=self.transitions.rewards,
                          parents=self.tree.parents, terminal=self.transitions.terminal)
@@ -299,6 +303,7 @@ class MCTS:
             _native.check(L.bl_sim_backup(s, self.sim, self._leaves.data_ptr(), logits.data_ptr(), kinds[logits.dtype],
                                           v.data_ptr(), kinds[v.dtype], st))
 
+    @profiling.roctx
     def simulate(self, network):
         if self.sim >= self.n_nodes:
             raise ValueError('Called simulate more times than were declared in the constructor')
@@ -324,6 +329,7 @@ class MCTS:
         probs = cuda.root(self._cuda())
         return (probs, None) if with_logits else probs
 
+    @profiling.roctx
     def root(self):
         r, logits = self.root_probs(with_logits=True)
         self._root_probs = r
@@ -434,12 +440,14 @@ class MCTSAgent:
         # prior and v are views of the tree: detach them from it, unless the caller (a graph replayer) clones anyway
         return d.clone() if clone else d
 
+    @profiling.roctx
     def __call__(self, world, value=True, eval=False, **kwargs):
         if not self.graph or kwargs or world.device.type != 'cuda':
             return self._move(world, eval, kwargs)
         key = (type(world), world.n_envs, world.boardsize, bool(eval), world.device)
         return self._graphed(key, lambda: _GraphedMove(self, world, eval))(world)
 
+    @profiling.roctx
     def play(self, world, eval=False):
         """One actor step of the self-play loop (boardlaw/main.py:176-177): decisions = agent(world); new_world,
         transition = world.step(decisions.actions).  With graph=True both halves replay as ONE captured graph (the env

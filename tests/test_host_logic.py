@@ -104,3 +104,30 @@ def test_dirichlet_noise_masks_and_renormalises():
     assert torch.isinf(out[~valid]).all() and torch.isfinite(out[valid]).all()
     assert torch.allclose(out.exp().sum(-1), torch.ones(5), atol=1e-5)
     assert torch.equal(dirichlet_noise(logits, valid, 0.).exp().argmax(-1), logits.argmax(-1))
+
+
+def test_roctx_ranges_follow_the_reference_switch(monkeypatch):
+    """rebar/profiling.py:15-28: markers only when the switch is set at decoration time; otherwise the function itself."""
+    from boardlaw_amd import profiling
+    def f(x):
+        return x + 1
+    monkeypatch.delenv('EMIT_ROCTX', raising=False); monkeypatch.delenv('EMIT_NVTX', raising=False)
+    assert profiling.roctx(f) is f
+    calls = []
+    monkeypatch.setenv('EMIT_NVTX', '1')
+    monkeypatch.setattr(profiling, 'push', lambda name: calls.append(('push', name)))
+    monkeypatch.setattr(profiling, 'pop', lambda: calls.append(('pop',)))
+    g = profiling.roctx(f)
+    assert g is not f and g(1) == 2 and g.__name__ == 'f'
+    assert calls[0][0] == 'push' and calls[0][1].endswith('f') and calls[1] == ('pop',)
+    def boom():
+        raise ValueError
+    h = profiling.nvtx(boom)
+    try:
+        h()
+    except ValueError:
+        pass
+    assert calls[-1] == ('pop',)          # the range is closed when the call raises
+    monkeypatch.undo()
+    lib = profiling._roctx()              # the ROCm image ships libroctx64: the real push/pop work without a GPU
+    assert profiling.push('boardlaw_amd.test') >= 0 and profiling.pop() >= 0
