@@ -44,11 +44,11 @@ def premix(worlds, moves, gen):
 
 
 class TimedExpand:
-    """Wraps the library's bl_sim_expand so that every launch inside the timed region is bracketed by HIP events on
-    the stream it is launched on (torch's current stream)."""
+    """Wraps one of the library's entry points (bl_sim_expand unless named) so that every launch inside the timed region is
+    bracketed by HIP events on the stream it is launched on (torch's current stream)."""
 
-    def __init__(self, lib):
-        self.lib, self.orig = lib, lib.bl_sim_expand
+    def __init__(self, lib, name='bl_sim_expand'):
+        self.lib, self.orig = lib, getattr(lib, name)
         self.pairs, self.on = [], False
 
     def __call__(self, *args):
@@ -253,6 +253,24 @@ def main():
             torch.cuda.synchronize()
             timer.on = False
         lib.bl_sim_expand = timer.orig
+        # SURVEY 8d "kernel-only sims/s (search kernels without the network)": the same moves with the finish step as its
+        # own launch (bl_mlp_forward_f16 + bl_sim_finish instead of bl_sim_infer_finish), both search kernels under HIP events
+        search_only = None
+        if not args.plain_network and not args.torch_gemms and default_shape:
+            t_exp, t_fin = TimedExpand(lib), TimedExpand(lib, 'bl_sim_finish')
+            lib.bl_sim_expand, lib.bl_sim_finish = t_exp, t_fin
+            split = MCTSAgent(agent.network, n_nodes=NODES, graph=False, rng=MoveRng(), fuse_finish=False)
+            w3 = split.play(worlds)[1]
+            t_exp.on = t_fin.on = True
+            for _ in range(2):
+                w3 = split.play(w3)[1]
+            torch.cuda.synchronize()
+            lib.bl_sim_expand, lib.bl_sim_finish = t_exp.orig, t_fin.orig
+            if t_fin.pairs:
+                search_only = {'sims_per_sec': args.envs / ((t_exp.mean_us() + t_fin.mean_us()) * 1e-6), 'bl_sim_expand_us': t_exp.mean_us(),
+                               'bl_sim_finish_us': t_fin.mean_us(),
+                               'note': 'envs / (bl_sim_expand + bl_sim_finish) per simulation, HIP events, network launched separately and not counted'}
+            del split, w3
         d, k, its = tree_statistics(worlds, net, NODES)
         kernel_us = timer.mean_us()
         per_launch = expand_bytes_per_env(A, S, d, k) * args.envs
@@ -276,6 +294,8 @@ def main():
                                    else 'fused MFMA kernel bl_sim_infer_finish (autocast rounding points; <= 1 f16 ulp vs autocast)') + '; root evaluation fp32',
                        'rng': 'MoveRng: torch generator, the T-1 descend uniforms of a move drawn as ONE (T-1,B,T) f16 block instead of T-1 rand_like calls',
                        'value_reference_rng_protocol': value_torch_rng,
+                       'search_kernels_only': search_only,
+                       'network_mfma_bound_sims_per_sec': 2.5e15 / (2 * (2 * A * WIDTH + DEPTH * WIDTH * WIDTH + WIDTH * (A + 1))),
                        'd_policy_evals_per_descent': round(d, 3), 'k_child_lookups_per_descent': round(k, 3),
                        'newton_iters_per_eval': round(its, 3),
                        'bytes_per_sim_whole_path': round(total_bytes_per_sim(A, S, NODES, d, k), 1),
