@@ -155,6 +155,7 @@ def main():
     ap.add_argument('--torch-gemms', action='store_true', help='keep the Linears as torch (hipBLASLt) GEMMs instead of the fused MFMA kernel')
     ap.add_argument('--timed-only', action='store_true', help='for profilers: only capture, warm-up and the timed moves; prints a reduced line')
     ap.add_argument('--no-reference-rng', action='store_true', help='skip the second timed region (torch rand_like per simulation)')
+    ap.add_argument('--no-two-actors', action='store_true', help='skip the two-actors-per-GPU region')
     ap.add_argument('--eager', action='store_true', help='launch kernel by kernel instead of replaying a HIP graph per move')
     args = ap.parse_args()
     respawn_per_gpu(args)
@@ -242,6 +243,35 @@ def main():
         value_torch_rng = args.envs * NODES * args.steps / (time.perf_counter() - t1)
         del ref_agent, w2
 
+    two_actors = None
+    if world == 1 and not args.eager and not args.no_two_actors and default_shape:
+        # NOT the metric (its configuration is ONE 4096-env search per GPU): a second, independent config-2 search resident on
+        # the same GPU, each actor replaying its captured moves on its own stream.  Both search kernels are latency-bound, so
+        # a second actor fills cycles the first leaves idle -- what a deployment that wants sims/s per GPU would run.
+        gen2 = torch.Generator(device='cuda'); gen2.manual_seed(2000 + rank)
+        pair = [Hex(board=worlds.board.clone(), seats=worlds.seats.clone()), premix(Hex.initial(args.envs, BOARD), BOARD * BOARD // 3, gen2)]
+        actors = [agent, MCTSAgent(agent.network, n_nodes=NODES, graph=True, rng=MoveRng())]
+        streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+        for s_ in streams:
+            s_.wait_stream(torch.cuda.current_stream())
+
+        def round_of_moves():
+            for i in range(2):
+                with torch.cuda.stream(streams[i]):
+                    pair[i] = actors[i].play(pair[i])[1]
+        for _ in range(3):
+            round_of_moves()
+            torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        for _ in range(args.steps):
+            round_of_moves()
+        torch.cuda.synchronize()
+        two_actors = {'sims_per_sec': 2 * args.envs * NODES * args.steps / (time.perf_counter() - t2), 'actors': 2, 'envs_per_actor': args.envs,
+                      'note': 'two independent config-2 searches on one GPU, one stream each (not the metric: 8192 envs resident)'}
+        for s_ in streams:
+            torch.cuda.current_stream().wait_stream(s_)
+        del actors, pair
+
     if rank == 0:
         A, S = BOARD * BOARD, 2
         if not args.eager:
@@ -295,6 +325,7 @@ def main():
                        'rng': 'MoveRng: torch generator, the T-1 descend uniforms of a move drawn as ONE (T-1,B,T) f16 block instead of T-1 rand_like calls',
                        'value_reference_rng_protocol': value_torch_rng,
                        'search_kernels_only': search_only,
+                       'two_actors_per_gpu': two_actors,
                        'network_mfma_bound_sims_per_sec': 2.5e15 / (2 * (2 * A * WIDTH + DEPTH * WIDTH * WIDTH + WIDTH * (A + 1))),
                        'd_policy_evals_per_descent': round(d, 3), 'k_child_lookups_per_descent': round(k, 3),
                        'newton_iters_per_eval': round(its, 3),
