@@ -250,7 +250,10 @@ def main():
         # a second actor fills cycles the first leaves idle -- what a deployment that wants sims/s per GPU would run.
         gen2 = torch.Generator(device='cuda'); gen2.manual_seed(2000 + rank)
         pair = [Hex(board=worlds.board.clone(), seats=worlds.seats.clone()), premix(Hex.initial(args.envs, BOARD), BOARD * BOARD // 3, gen2)]
-        actors = [agent, MCTSAgent(agent.network, n_nodes=NODES, graph=True, rng=MoveRng())]
+        gens = [torch.Generator(device='cuda'), torch.Generator(device='cuda')]
+        gens[0].manual_seed(3000 + rank); gens[1].manual_seed(4000 + rank)
+        # a generator per actor: concurrently replayed graphs on one generator race for its Philox offset (MoveRng.__init__)
+        actors = [MCTSAgent(agent.network, n_nodes=NODES, graph=True, rng=MoveRng(generator=g)) for g in gens]
         streams = [torch.cuda.Stream(), torch.cuda.Stream()]
         for s_ in streams:
             s_.wait_stream(torch.cuda.current_stream())

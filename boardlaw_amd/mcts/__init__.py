@@ -48,16 +48,20 @@ class MoveRng(TorchRng):
     TorchRng (the generator is consumed in one block), which on a GPU is unobservable against the reference (its CUDA
     stream differs per device anyway).  Opt-in: MCTS(..., rng=MoveRng())."""
 
-    def __init__(self):
-        self.block, self.i = None, 0
+    def __init__(self, generator=None):
+        """generator: a torch.Generator on the search's device, or None for torch's default one.  Searches that replay
+        captured moves CONCURRENTLY (several actors on one GPU, each on its own stream) need a generator each: a captured
+        graph reads its Philox offset from a tensor the generator owns and refills before every replay, so two graphs on
+        one generator race for it (and, being the same graph, would draw the same numbers)."""
+        self.block, self.i, self.generator = None, 0, generator
 
     def start(self, n_calls, like):
-        self.block = torch.rand((n_calls,) + tuple(like.shape), dtype=like.dtype, device=like.device)
+        self.block = torch.rand((n_calls,) + tuple(like.shape), dtype=like.dtype, device=like.device, generator=self.generator)
         self.i = 0
 
     def rand_like(self, x):
         if self.block is None or self.i >= self.block.shape[0] or self.block.shape[1:] != x.shape:
-            return torch.rand_like(x)
+            return torch.rand(x.shape, dtype=x.dtype, device=x.device, generator=self.generator)
         r = self.block[self.i]
         self.i += 1
         return r
@@ -68,12 +72,12 @@ class MoveRng(TorchRng):
         """Unnormalised Dirichlet draw: the Gamma(alpha, 1) variates torch's Dirichlet sampler starts from
         (torch._sample_dirichlet = standard_gamma / sum).  bl_sim_plant_root normalises over the valid actions anyway
         (mcts/__init__.py:19-22), so the intermediate normalisation over all actions is dropped."""
-        return torch._standard_gamma(alpha.expand(*shape, alpha.shape[-1]))
+        return torch._standard_gamma(alpha.expand(*shape, alpha.shape[-1]), self.generator)
 
     def draw_actions(self, probs):
         """Categorical(probs / probs.sum()) by inverse CDF from one torch.rand per env (bl_draw_actions)."""
         B, A = probs.shape
-        u = torch.rand((B,), dtype=torch.float, device=probs.device)
+        u = torch.rand((B,), dtype=torch.float, device=probs.device, generator=self.generator)
         actions = torch.empty((B,), dtype=torch.long, device=probs.device)
         with torch.cuda.device(probs.device):
             _native.check(_native.lib().bl_draw_actions(probs.contiguous().data_ptr(), u.data_ptr(), actions.data_ptr(), B, A,
@@ -501,6 +505,9 @@ class _GraphedMove:
                 run()                                   # warm-up: builds lookup tables, lets hipBLASLt pick kernels
             torch.cuda.current_stream().wait_stream(side)
             self.graph = torch.cuda.CUDAGraph()
+            generator = getattr(agent.kwargs.get('rng'), 'generator', None)
+            if generator is not None:
+                self.graph.register_generator_state(generator)      # a private generator's offsets must be graph-managed too
             with torch.cuda.graph(self.graph):
                 self.out = run()
         self.kind = kind

@@ -995,3 +995,46 @@ def test_copy_many_clones_every_layout(n):
     assert all(torch.equal(a, b) for a, b in zip(dsts, out))
     with pytest.raises(_native.NativeError):
         _native.copy_many([torch.empty(4, device=DEV)], [torch.empty(5, device=DEV)])
+
+
+def test_two_actors_on_two_streams_equal_the_same_calls_on_one():
+    """Two independent searches resident on one GPU, each replaying its captured moves on its own stream (what
+    bench.py's two_actors_per_gpu region and tools/multi_actor_probe.py time): the kernels of the two actors interleave
+    on the device, the host issues the calls in the same order either way, so every decision and every world must be
+    identical to the same calls made on a single stream."""
+    from boardlaw_amd import hex, networks
+    from boardlaw_amd.mcts import MCTSAgent, MoveRng
+
+    def play(concurrent):
+        torch.manual_seed(11)
+        net = networks.FCModel(hex.Hex.initial(1, 9, device=DEV).obs_space, hex.Hex.initial(1, 9, device=DEV).action_space, width=256, depth=2).to(DEV)
+        inf = networks.Inference(net, fused=True)
+        worlds = []
+        for i in range(2):
+            w = hex.Hex.initial(1024, 9, device=DEV)
+            for _ in range(10 + i):
+                r = torch.rand(w.valid.shape, device=DEV) * w.valid
+                w, _ = w.step(r.argmax(-1), check=False)
+            worlds.append(w)
+        gens = [torch.Generator(device=DEV) for _ in range(2)]
+        for i, g in enumerate(gens):
+            g.manual_seed(100 + i)
+        # a generator per actor: two captured graphs on one generator race for its offset tensor (MoveRng.__init__)
+        agents = [MCTSAgent(inf, n_nodes=32, graph=True, rng=MoveRng(generator=gens[i])) for i in range(2)]
+        streams = [torch.cuda.Stream(), torch.cuda.Stream()] if concurrent else [torch.cuda.current_stream()] * 2
+        torch.cuda.synchronize()
+        out = []
+        for move in range(4):
+            for i in range(2):
+                with torch.cuda.stream(streams[i]):
+                    d, worlds[i], tr = agents[i].play(worlds[i])
+                out.append((d, worlds[i], tr))
+        torch.cuda.synchronize()
+        return out
+
+    a, b = play(True), play(False)
+    for (da, wa, ta), (db, wb, tb) in zip(a, b):
+        for k in ('logits', 'prior', 'v', 'actions', 'n_leaves', 'n_sims'):
+            assert torch.equal(da[k], db[k]) or (da[k].dtype.is_floating_point and np.array_equal(bits16(da[k]), bits16(db[k]))), k
+        assert torch.equal(wa.board, wb.board) and torch.equal(wa.seats, wb.seats)
+        assert torch.equal(ta.terminal, tb.terminal) and torch.equal(ta.rewards, tb.rewards)

@@ -23,7 +23,7 @@ for G in (1, 2, 3, 4):
             net = networks.FCModel(w.obs_space, w.action_space, 512, 4).cuda()
             inf = networks.Inference(net, fused=True)
         worlds.append(premix(w, 27, g))
-    agents = [MCTSAgent(inf, n_nodes=NODES, graph=True, rng=MoveRng()) for _ in range(G)]
+    agents = [MCTSAgent(inf, n_nodes=NODES, graph=True, rng=MoveRng(generator=gens[i])) for i in range(G)]     # a generator per actor
     streams = [torch.cuda.Stream() for _ in range(G)]
     for _ in range(3):                                   # capture + warm-up
         for i in range(G):
