@@ -9,6 +9,7 @@
 // The heads' nonlinearities (masked log-softmax, tanh) stay in bl_sim_finish.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include "../../include/boardlaw_amd.h"
 
 namespace blmlp {
@@ -39,6 +40,7 @@ struct Params {
     uint16_t* policy;         // (M, NH-1)
     uint16_t* value;          // (M)
     int M, K0, K0pad, W, D, NH, NHpad;
+    int xcd_rows;             // 1: tile i takes rows 256*(i/8) + 8*r + i%8 (rows whose index is i mod 8), else rows 32*i + r
 };
 
 // What bl_sim_finish does for a leaf (heads, store, backup, next q range), as this kernel's epilogue: bl_sim_infer_finish.
@@ -195,7 +197,13 @@ __global__ void __launch_bounds__(WAVES * 64) mlp_kernel(Params p, FinArgs f) {
     uint16_t* R0 = (uint16_t*)smem;
     const int par0 = (p.D + 1) & 1;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int row0 = blockIdx.x * 32;
+    // Which 32 batch rows this workgroup takes.  Workgroup i runs on XCD i % 8 and so does bl_sim_expand's workgroup for env
+    // b = i mod 8 (one workgroup per env, placed the same way): with xcd_rows a tile is made of envs of its own XCD, so what
+    // the search kernel just wrote for them (observation, path, leaf) and what this kernel writes for the next descent
+    // (logits, compacted row, w, n) stay within one XCD's L2 instead of crossing the fabric.  Placement is a speed matter
+    // only: any mapping gives the same results.
+    const int tile_j = blockIdx.x >> 3, tile_x = blockIdx.x & 7;
+    auto grow = [&](int r) { return p.xcd_rows ? 256 * tile_j + 8 * r + tile_x : (int)blockIdx.x * 32 + r; };
     constexpr int NTHREADS = WAVES * 64;
     const int brow = lane & 31, hf = lane >> 5;     // this lane's batch row within the tile, and its feature half
 
@@ -229,7 +237,7 @@ __global__ void __launch_bounds__(WAVES * 64) mlp_kernel(Params p, FinArgs f) {
 #pragma unroll
                 for (int k = 0; k < WMAX; k++) {
                     const int w = c + 32 * k;
-                    st[i][k] = (w < wvalid && row0 + r < p.M) ? src[(long)(row0 + r) * wvalid + w] : 0u;
+                    st[i][k] = (w < wvalid && grow(r) < p.M) ? src[(long)grow(r) * wvalid + w] : 0u;
                 }
             }
             CLK(50)
@@ -245,7 +253,7 @@ __global__ void __launch_bounds__(WAVES * 64) mlp_kernel(Params p, FinArgs f) {
             gemm_prefetch<NT>(rg, p.w0, p.K0pad, wave * PASSES * NT, NT);
             for (int r = r_first; r < 32; r += NTHREADS / 32)
                 for (int w = c; w < wpr; w += 32)
-                    dst[r * (ld >> 1) + w] = (w < wvalid && row0 + r < p.M) ? src[(long)(row0 + r) * wvalid + w] : 0u;
+                    dst[r * (ld >> 1) + w] = (w < wvalid && grow(r) < p.M) ? src[(long)grow(r) * wvalid + w] : 0u;
         }
     }
     CLK(52)
@@ -254,7 +262,7 @@ __global__ void __launch_bounds__(WAVES * 64) mlp_kernel(Params p, FinArgs f) {
     if constexpr (FINISH) {
 #pragma unroll
         for (int e = 0; e < EPW; e++) {
-            const int b = row0 + EPW * wave + e;
+            const int b = grow(EPW * wave + e);
             fb[e] = b < p.M ? b : -1;
             const long bb = b < p.M ? b : 0;
             fleaf[e] = f.leaves[bb]; fmover[e] = f.leaf_seats[bb];
@@ -390,11 +398,11 @@ __global__ void __launch_bounds__(WAVES * 64) mlp_kernel(Params p, FinArgs f) {
     if constexpr (!FINISH) {
         // coalesced stores: a wave writes one row's NH-1 policy outputs as consecutive halves
         for (int r = wave; r < 32; r += WAVES) {
-            if (row0 + r < p.M) {
-                for (int fi = lane; fi < p.NH - 1; fi += 64) p.policy[(long)(row0 + r) * (p.NH - 1) + fi] = Out[r * p.NHpad + fi];
+            if (grow(r) < p.M) {
+                for (int fi = lane; fi < p.NH - 1; fi += 64) p.policy[(long)grow(r) * (p.NH - 1) + fi] = Out[r * p.NHpad + fi];
             }
         }
-        if (tid < 32 && row0 + tid < p.M) p.value[row0 + tid] = Out[tid * p.NHpad + p.NH - 1];
+        if (tid < 32 && grow(tid) < p.M) p.value[grow(tid)] = Out[tid * p.NHpad + p.NH - 1];
     } else {
         // ---- bl_sim_finish's work for this wave's four envs, operation for operation as in bl_kernels.hip:
         // sim_finish_kernel (heads with torch's order; backup cuda.cu:205-236; transition_q's range), but PHASE by phase
@@ -584,7 +592,7 @@ static int mlp_launch(const blmlp::Params& p, const blmlp::FinArgs* fin, bl_stre
     const size_t staging = (size_t)(NHpad / 32) * 16 * 64 * 4 + (size_t)32 * NHpad * 2 + (fin ? 8 * 4 * 128 * 4 : 0);
     const size_t lds = buf + (staging > buf ? staging : buf);
     if (lds > 160 * 1024) return BL_ETOOBIG;
-    const dim3 grid((M + 31) / 32);
+    const dim3 grid(p.xcd_rows ? 8 * ((M + 255) / 256) : (M + 31) / 32);
     hipStream_t hs = (hipStream_t)stream;
     const FinArgs f = fin ? *fin : FinArgs{};
     // above the 64 KiB default the limit has to be raised per kernel (gfx950 has 160 KiB per CU)
@@ -627,7 +635,7 @@ extern "C" int bl_mlp_forward_f16(const void* obs, int M, int K0, const void* w0
     if (!policy_out || !value_out) return BL_EINVAL;
     if (int rc = mlp_check(obs, M, K0, w0, b0, wb, bb, alphas, wh, bh, W, D, K0pad, NH, NHpad)) return rc;
     Params p{(const uint16_t*)obs, (const uint16_t*)w0, (const uint16_t*)b0, (const uint16_t*)wb, (const uint16_t*)bb, alphas,
-             (const uint16_t*)wh, (const uint16_t*)bh, (uint16_t*)policy_out, (uint16_t*)value_out, M, K0, K0pad, W, D, NH, NHpad};
+             (const uint16_t*)wh, (const uint16_t*)bh, (uint16_t*)policy_out, (uint16_t*)value_out, M, K0, K0pad, W, D, NH, NHpad, 0};
     return mlp_launch(p, nullptr, stream);
 }
 
@@ -641,8 +649,9 @@ extern "C" int bl_sim_infer_finish(const bl_search_t* s, int sim, const int16_t*
     const int A = s->boardsize * s->boardsize, M = s->B, K0 = 2 * A, NH = A + 1;
     if (s->T > 64 || A > 128 || W < 256) return BL_ETOOBIG;     // the epilogue keeps a whole env in one wave's registers
     if (int rc = mlp_check(obs, M, K0, w0, b0, wb, bb, alphas, wh, bh, W, D, K0pad, NH, NHpad)) return rc;
+    static const int xcd_rows = getenv("BL_MLP_XCD") ? atoi(getenv("BL_MLP_XCD")) != 0 : 1;     // tiles of same-XCD envs (see mlp_kernel)
     Params p{(const uint16_t*)obs, (const uint16_t*)w0, (const uint16_t*)b0, (const uint16_t*)wb, (const uint16_t*)bb, alphas,
-             (const uint16_t*)wh, (const uint16_t*)bh, nullptr, nullptr, M, K0, K0pad, W, D, NH, NHpad};
+             (const uint16_t*)wh, (const uint16_t*)bh, nullptr, nullptr, M, K0, K0pad, W, D, NH, NHpad, xcd_rows};
     int np2 = 1; while (np2 < A) np2 *= 2;
     const int Wsm = np2 < 64 ? np2 : 64;
     FinArgs f{(uint16_t*)s->logits, (uint16_t*)s->v, (uint16_t*)s->w, s->n, (const uint16_t*)s->rewards, s->terminal, s->path,
