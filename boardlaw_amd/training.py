@@ -53,26 +53,59 @@ def optimize(network, scaler, opt, batch, sync_gradients=True):
 def run(worlds, network, n_steps, nodes=64, c_puct=1 / 16, lr=1e-3, buffer_len=64, graph=False, inference=None, on_step=None):
     """main.py:147-200 minus run bookkeeping.  `worlds` is this rank's env shard.  Returns the final worlds.
     inference: None (the module under autocast, as the reference), 'torch' or 'fused' (networks.Inference plans; their
-    f16 weights are refreshed from the module at the start of every move, so optimiser steps are seen)."""
+    f16 weights are refreshed from the module at the start of every move, so optimiser steps are seen).
+
+    `worlds` may also be a list of independent env batches -- several ACTORS on this GPU sharing the network.  Each actor
+    searches on its own stream with its own generator (the search kernels are latency-bound, so a second resident search
+    fills the cycles the first leaves idle: DESIGN.md section 5), keeps its own buffer, and the learner takes one step per
+    actor chunk in turn -- what that many reference processes sharing one set of weights would do.  Returns the list."""
     from . import networks
-    from .mcts import MCTSAgent
-    n_envs, dev = worlds.n_envs, worlds.device
+    from .mcts import MCTSAgent, MoveRng
+    many = isinstance(worlds, (list, tuple))
+    batches = list(worlds) if many else [worlds]
+    dev = batches[0].device
     actor = network if inference is None else networks.Inference(network, fused=(inference == 'fused'))
-    agent = MCTSAgent(actor, n_nodes=nodes, c_puct=c_puct, graph=graph)
+    concurrent = many and len(batches) > 1 and dev.type == 'cuda'
+    agents, streams = [], []
+    for i in range(len(batches)):
+        kwargs = {}
+        if concurrent:
+            gen = torch.Generator(device=dev)
+            gen.manual_seed(int(torch.randint(2 ** 31 - 1, (1,)).item()))      # seeded from the default generator: reproducible
+            kwargs['rng'] = MoveRng(generator=gen)
+            streams.append(torch.cuda.Stream(device=dev))
+        agents.append(MCTSAgent(actor, n_nodes=nodes, c_puct=c_puct, graph=graph, **kwargs))
     opt = torch.optim.Adam(network.parameters(), lr=lr)
     scaler = torch.amp.GradScaler('cuda', enabled=(dev.type == 'cuda'))
-    idxs = (torch.randint(buffer_len, (n_envs,), device=dev), torch.arange(n_envs, device=dev))
-    buffer = []
-    for step in range(n_steps):
-        while len(buffer) < buffer_len:
-            with torch.no_grad():
-                decisions = agent(worlds, value=True)
-            new_worlds, transition = worlds.step(decisions.actions)
-            buffer.append(arrdict.arrdict(worlds=worlds, decisions=decisions.half(),
+    idxs = [(torch.randint(buffer_len, (w.n_envs,), device=dev), torch.arange(w.n_envs, device=dev)) for w in batches]
+    buffers = [[] for _ in batches]
+
+    def move(i):
+        with torch.no_grad():
+            decisions = agents[i](batches[i], value=True)
+        new_worlds, transition = batches[i].step(decisions.actions)
+        buffers[i].append(arrdict.arrdict(worlds=batches[i], decisions=decisions.half(),
                                           transitions=learning.half(transition)).detach())
-            worlds = new_worlds
-        chunk, buffer = as_chunk(buffer, n_envs)
-        pl, vl = optimize(network, scaler, opt, chunk[idxs])
-        if on_step is not None:
-            on_step(step, pl, vl)
-    return worlds
+        batches[i] = new_worlds
+
+    for step in range(n_steps):
+        while any(len(b) < buffer_len for b in buffers):
+            for i in range(len(batches)):
+                if len(buffers[i]) < buffer_len:
+                    if concurrent:
+                        with torch.cuda.stream(streams[i]):
+                            move(i)
+                    else:
+                        move(i)
+        if concurrent:
+            for s_ in streams:                                  # the learner reads what the actors' streams produced ...
+                torch.cuda.current_stream(dev).wait_stream(s_)
+        for i in range(len(batches)):
+            chunk, buffers[i] = as_chunk(buffers[i], batches[i].n_envs)
+            pl, vl = optimize(network, scaler, opt, chunk[idxs[i]])
+            if on_step is not None:
+                on_step(step, pl, vl)
+        if concurrent:
+            for s_ in streams:                                  # ... and the next moves see the updated weights (and freed blocks)
+                s_.wait_stream(torch.cuda.current_stream(dev))
+    return batches if many else batches[0]

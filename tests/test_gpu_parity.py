@@ -590,6 +590,32 @@ def test_actor_learner_loop_runs_and_learns_something(inference, graph):
     assert (after - before).abs().max() > 0
 
 
+def test_actor_learner_loop_with_two_actors_on_one_gpu():
+    """training.run with a list of env batches: two actors searching concurrently (own stream, own generator, captured
+    moves, fused plans), one learner step per actor chunk.  Same seed => same losses, bit for bit, whatever the overlap on
+    the device; the actors play different games; the weights move."""
+    from boardlaw_amd import hex, networks, training
+
+    def once():
+        torch.manual_seed(5)
+        batches = [hex.Hex.initial(512, 5, device=DEV), hex.Hex.initial(512, 5, device=DEV)]
+        net = networks.FCModel(batches[0].obs_space, batches[0].action_space, width=128, depth=2).to(DEV)
+        before = torch.cat([p.detach().flatten().clone() for p in net.parameters()])
+        log = []
+        out = training.run(batches, net, n_steps=3, nodes=16, buffer_len=4, graph=True, inference='fused',
+                           on_step=lambda i, pl, vl: log.append((float(pl), float(vl))))
+        torch.cuda.synchronize()
+        after = torch.cat([p.detach().flatten() for p in net.parameters()])
+        return log, out, before, after
+
+    log, out, before, after = once()
+    assert isinstance(out, list) and len(out) == 2 and len(log) == 6 and all(np.isfinite(x).all() for x in log)
+    assert (after - before).abs().max() > 0
+    assert not torch.equal(out[0].board, out[1].board)
+    log2, out2, _, after2 = once()
+    assert log2 == log and torch.equal(after2, after) and all(torch.equal(a.board, b.board) for a, b in zip(out, out2))
+
+
 def test_arena_evaluate_with_search_agents():
     """arena.common.evaluate with two MCTS agents on Hex -- masked, variable-size batches, argmax actions."""
     from boardlaw_amd import arena, hex, networks
