@@ -13,6 +13,7 @@ from test_oracle import OPS, SEARCHES, gold, op_cases, random_tree, bits
 
 pytestmark = pytest.mark.gpu
 DEV = 'cuda'
+SEED = int(os.environ.get('BL_TEST_SEED', '0'))      # tools/fuzz_parity.sh: the full-size oracle comparisons on other positions and draws
 
 
 @pytest.fixture(scope='module', autouse=True)
@@ -242,8 +243,8 @@ def test_full_size_search_vs_oracle(oracle, S, B, T):
     the oracle-driven search on the host, with a device-independent integer network.  Everything must be identical."""
     from boardlaw_amd.hex import Hex
     from boardlaw_amd.mcts import MCTS
-    board, seats = premixed(oracle, B, S, (S * S) // 3, seed=S * 1000 + T)
-    rng = np.random.default_rng(1)
+    board, seats = premixed(oracle, B, S, (S * S) // 3, seed=S * 1000 + T + SEED)
+    rng = np.random.default_rng(1 + SEED)
     rands = rng.random((T - 1, B, T)).astype(np.float16).view(np.uint16)
     want = oracle_search(oracle, board, seats, T, rands)
 
@@ -905,9 +906,9 @@ def test_bench_launch_sequence_vs_oracle(oracle, S, B, T, width, depth, mode):
     from boardlaw_amd import networks
     from boardlaw_amd.hex import Hex
     from boardlaw_amd.mcts import MCTS, MoveRng, TorchRng, mcts
-    board, seats = premixed(oracle, B, S, (S * S) // 3, seed=31 * S + T)
+    board, seats = premixed(oracle, B, S, (S * S) // 3, seed=31 * S + T + SEED)
     world = Hex(board=torch.from_numpy(board).to(DEV), seats=torch.from_numpy(seats).to(DEV))
-    torch.manual_seed(5)
+    torch.manual_seed(5 + SEED)
     net = networks.Inference(networks.FCModel(world.obs_space, world.action_space, width=width, depth=depth).to(DEV),
                              fused=(mode != 'eager-torch-gemms'))
     with torch.no_grad():
