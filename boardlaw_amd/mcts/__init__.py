@@ -278,7 +278,7 @@ class MCTS:
                                                       self._obs.data_ptr(), self._valid.data_ptr(),
                                                       self._leaf_seats.data_ptr(), self.counters.data_ptr(), st))
             world = LeafWorlds(self, self._leaves, self._obs, self._valid, self._leaf_seats)
-            fp = network.fused_params() if (self.fuse_finish and hasattr(network, 'fused_params')) else None
+            fp = network.fused_params(self.n_envs) if (self.fuse_finish and hasattr(network, 'fused_params')) else None
             if (fp is not None and self._obs.dtype == torch.half and self.n_nodes <= 64 and self.n_actions <= 128
                     and fp['W'] >= 256 and fp['K0'] == 2 * self.n_actions and fp['NH'] == self.n_actions + 1):
                 # one launch: the network's Linears, its heads, the store, the backup and the next q range

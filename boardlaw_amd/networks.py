@@ -69,6 +69,12 @@ class Inference:
 
     wants_half_obs = True
     ROOT_FUSED_MIN_ROWS = 2048
+    # bl_mlp_forward_f16's time is one workgroup's chain: every 32-row workgroup streams ALL the weights through its CU's L1
+    # (64 B/clk).  Up to FUSED_ALWAYS_BYTES of weights (512x4: 2.4 MB, 28 us) that beats a launch per Linear at any batch size;
+    # beyond it (1024x8: 17.9 MB, 170 us) only once the batch gives FUSED_MIN_TILES workgroups -- at 13x13 / 1024 rows the
+    # library GEMMs, which split every Linear over all CUs, finish a move in 59 ms against 69.
+    FUSED_ALWAYS_BYTES = 6 << 20
+    FUSED_MIN_TILES = 64
 
     def __init__(self, model, fused=False):
         """fused=True additionally runs all Linears as ONE MFMA kernel (bl_mlp_forward_f16) when the width is a multiple
@@ -243,12 +249,20 @@ class Inference:
                 return out[:, :-1], out[:, -1]
             return F.linear(x, m.policy.core.weight, m.policy.core.bias), F.linear(x, m.value.core.weight, m.value.core.bias).squeeze(-1)
 
-    def fused_params(self):
+    def prefers_fused(self, rows):
+        """Whether the one-kernel plan is the faster one for a batch of `rows` (see FUSED_ALWAYS_BYTES)."""
+        if not (self.fused and self._packed is not None):
+            return False
+        W, K0, K0pad, D, NH, NHpad = self._packed['dims']
+        streamed = 2 * (W * K0pad + D * W * W + NHpad * W)
+        return streamed <= self.FUSED_ALWAYS_BYTES or -(-rows // 32) >= self.FUSED_MIN_TILES
+
+    def fused_params(self, rows=None):
         """Pointers and dims of the packed f16 weights for bl_sim_infer_finish, or None when the plan is not the fused
         kernel's (then the caller uses raw() + bl_sim_finish)."""
         if self._static is None:
             self.refresh()
-        if not (self.fused and self._packed is not None):
+        if not (self.fused and self._packed is not None) or (rows is not None and not self.prefers_fused(rows)):
             return None
         pk = self._packed
         W, K0, K0pad, D, NH, NHpad = pk['dims']
@@ -265,7 +279,7 @@ class Inference:
         obs = worlds.obs
         x0 = obs.reshape(obs.shape[0], -1).half().contiguous()
         st = _native.stream(x0.device)
-        if self.fused and self._packed is not None:
+        if self.fused and self._packed is not None and self.prefers_fused(x0.shape[0]):
             pk = self._packed
             W, K0, K0pad, D, NH, NHpad = pk['dims']
             M = x0.shape[0]

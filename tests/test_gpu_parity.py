@@ -530,8 +530,9 @@ def test_fused_mlp_matches_autocast(S, width, depth, B):
     class W_: pass
     w = W_(); w.obs = (torch.rand(B, S, S, 2, device=DEV) < .3).half()
     fused = networks.Inference(net, fused=True)
+    fused.FUSED_MIN_TILES = 0          # the kernel at every shape (the plan itself leaves wide networks on small batches to the GEMMs)
     fused.refresh()
-    assert fused._packed is not None
+    assert fused._packed is not None and fused.prefers_fused(B)
     with torch.no_grad(), torch.autocast('cuda'):
         p0, v0 = net.raw(w)
         p1, v1 = fused.raw(w)
@@ -915,6 +916,7 @@ def test_bench_launch_sequence_vs_oracle(oracle, S, B, T, width, depth, mode):
         for p_ in net.model.parameters():
             if p_.ndim == 0:
                 p_.fill_(0.3)          # ReZero gains start at 0: make the evaluation depend on the position
+    net.FUSED_MIN_TILES = 0            # keep bl_mlp_forward_f16 on the 13x13 / 1024-row case (the plan would pick the GEMMs there)
     net.refresh()
     if mode == 'graph':
         rng = MoveRng()
@@ -1065,3 +1067,23 @@ def test_two_actors_on_two_streams_equal_the_same_calls_on_one():
             assert torch.equal(da[k], db[k]) or (da[k].dtype.is_floating_point and np.array_equal(bits16(da[k]), bits16(db[k]))), k
         assert torch.equal(wa.board, wb.board) and torch.equal(wa.seats, wb.seats)
         assert torch.equal(ta.terminal, tb.terminal) and torch.equal(ta.rewards, tb.rewards)
+
+
+def test_inference_plan_selection():
+    """Inference picks the one-kernel plan by what bounds it (one workgroup streams all the weights): always for 512x4,
+    for 1024x8 only when the batch fills 64 workgroups; MCTS.simulate follows (fused finish or raw() + bl_sim_finish)."""
+    from boardlaw_amd import hex, networks
+    from boardlaw_amd.mcts import mcts
+    w = hex.Hex.initial(8, 9, device=DEV)
+    small = networks.Inference(networks.FCModel(w.obs_space, w.action_space, width=512, depth=4).to(DEV), fused=True); small.refresh()
+    wide = networks.Inference(networks.FCModel(w.obs_space, w.action_space, width=1024, depth=8).to(DEV), fused=True); wide.refresh()
+    assert small.prefers_fused(1) and small.prefers_fused(4096) and small.fused_params(8) is not None
+    assert not wide.prefers_fused(1024) and wide.prefers_fused(2048) and wide.prefers_fused(4096)
+    assert wide.fused_params(1024) is None and wide.fused_params(4096) is not None and wide.fused_params() is not None
+    assert not networks.Inference(small.model, fused=False).prefers_fused(4096)
+    torch.manual_seed(0)
+    a = mcts(w, wide, n_nodes=8)                       # 8 rows of 1024x8: the GEMM plan + bl_sim_finish
+    wide.FUSED_MIN_TILES = 0
+    torch.manual_seed(0)
+    b = mcts(w, wide, n_nodes=8)                       # the same search through bl_sim_infer_finish
+    assert (to_np(a.stats.n)[:, 0] == 14).all() and (to_np(b.stats.n)[:, 0] == 14).all()
