@@ -104,3 +104,30 @@ def test_bench_two_ranks_on_one_gpu():
                {'BENCH_BACKEND': 'gloo', 'BENCH_FORCE_DEVICE': '0'})
     assert d['n_gpus'] == 2 and d['config']['parallelism'] == 'replicas x2' and d['value'] > 0
     assert d['scaling'] == 'weak'
+
+
+@pytest.mark.gpu
+def test_rccl_collectives_on_the_device():
+    """The collectives the sharded path uses -- barrier, MAX over ranks (float64), the q-range all-reduce (int64 MAX) -- through
+    RCCL itself on the GPU, in a one-rank group (the pool's boxes have one GPU; N > 1 ranks are covered over gloo): the
+    communicator comes up in this environment and the dtypes/ops exist in RCCL."""
+    import subprocess, sys
+    code = '''
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, %r)
+from boardlaw_amd import parallel
+os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT='29541')
+dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))
+parallel.barrier()
+assert parallel.max_over_ranks(1.25) == 1.25 and parallel.sum_over_ranks(2.5) == 2.5
+state = torch.tensor([[-1, 5, -2**31, 2**31 - 1]], dtype=torch.int32, device='cuda')
+want = state.clone()
+assert torch.equal(parallel.allreduce_qrange(state), want)
+flat = torch.arange(8, dtype=torch.float32, device='cuda')
+dist.all_reduce(flat); torch.cuda.synchronize()
+assert dist.get_backend() == 'nccl'
+dist.destroy_process_group()
+print('rccl ok')
+''' % ROOT
+    r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and 'rccl ok' in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
