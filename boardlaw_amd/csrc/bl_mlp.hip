@@ -121,22 +121,26 @@ __device__ __forceinline__ void ring_load(half8 (&b)[NT][4], const uint16_t* Wp,
 // Starts a layer's weight stream (k blocks 0 and 1).  Called BEFORE the previous layer's epilogue and barriers: weights
 // do not depend on activations, so their L2 latency hides behind that work.
 template <int NT>
-__device__ __forceinline__ void gemm_prefetch(Ring<NT>& rg, const uint16_t* Wp, int K, int tile0, int ntiles_valid) {
+__device__ __forceinline__ void gemm_prefetch(Ring<NT>& rg, const uint16_t* Wp, int K, int tile0, int ntiles_valid, int rot = 0) {
     const int KB = K >> 6;
-    ring_load<NT>(rg.b0, Wp, KB, tile0, ntiles_valid, 0);
-    if (KB > 1) ring_load<NT>(rg.b1, Wp, KB, tile0, ntiles_valid, 1);
+    ring_load<NT>(rg.b0, Wp, KB, tile0, ntiles_valid, rot);
+    if (KB > 1) ring_load<NT>(rg.b1, Wp, KB, tile0, ntiles_valid, rot + 1 < KB ? rot + 1 : rot + 1 - KB);
 }
 
 // Runs the layer: three k blocks of weight fragments in flight (their L2 latency, 1-2k cycles under load, is several
 // blocks of MFMA work and a wave has only one partner on its SIMD to hide behind).
+// `rot`: the k blocks are taken in the order rot, rot+1, ... (mod KB).  With `own_first` the wave's first block is the one it
+// wrote itself in the previous layer's epilogue (its 64 output features ARE k block `wave` of this layer when W = 512), so
+// it is consumed BEFORE the layer barrier, which then hides behind 1/8 of the GEMM instead of standing in front of it.
 template <int NT>
 __device__ __forceinline__ void gemm_run(Ring<NT>& rg, const uint16_t* in, int ldin, const uint16_t* Wp, int K, int tile0,
-                                         int ntiles_valid, float16v (&acc)[NT]) {
+                                         int ntiles_valid, float16v (&acc)[NT], int rot = 0, bool own_first = false) {
     const int lane = threadIdx.x & 63, r = lane & 31, hf = lane >> 5;
     const int KB = K >> 6;
 #pragma unroll
     for (int t = 0; t < NT; t++) for (int i = 0; i < 16; i++) acc[t][i] = 0.f;
     const uint16_t* arow = in + r * ldin + 32 * hf;
+    auto blk = [&](int i) { const int kb = rot + i; return kb < KB ? kb : kb - KB; };
     auto compute = [&](half8 (&b)[NT][4], int kb) {
         half8 a[4];
 #pragma unroll
@@ -147,16 +151,17 @@ __device__ __forceinline__ void gemm_run(Ring<NT>& rg, const uint16_t* in, int l
             for (int t = 0; t < NT; t++) if (t < ntiles_valid) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b[t][s], a[s], acc[t], 0, 0, 0);
         }
     };
-    for (int kb = 0; kb < KB; kb += 3) {
-        if (kb + 2 < KB) ring_load<NT>(rg.b2, Wp, KB, tile0, ntiles_valid, kb + 2);
-        compute(rg.b0, kb);
-        if (kb + 1 < KB) {
-            if (kb + 3 < KB) ring_load<NT>(rg.b0, Wp, KB, tile0, ntiles_valid, kb + 3);
-            compute(rg.b1, kb + 1);
+    for (int i = 0; i < KB; i += 3) {
+        if (i + 2 < KB) ring_load<NT>(rg.b2, Wp, KB, tile0, ntiles_valid, blk(i + 2));
+        compute(rg.b0, blk(i));
+        if (i == 0 && own_first) __syncthreads();
+        if (i + 1 < KB) {
+            if (i + 3 < KB) ring_load<NT>(rg.b0, Wp, KB, tile0, ntiles_valid, blk(i + 3));
+            compute(rg.b1, blk(i + 1));
         }
-        if (kb + 2 < KB) {
-            if (kb + 4 < KB) ring_load<NT>(rg.b1, Wp, KB, tile0, ntiles_valid, kb + 4);
-            compute(rg.b2, kb + 2);
+        if (i + 2 < KB) {
+            if (i + 4 < KB) ring_load<NT>(rg.b1, Wp, KB, tile0, ntiles_valid, blk(i + 4));
+            compute(rg.b2, blk(i + 2));
         }
     }
 }
@@ -283,6 +288,12 @@ __global__ void __launch_bounds__(WAVES * 64) mlp_kernel(Params p, FinArgs f) {
     // intake Linear, then the ReZero blocks (networks.py:17-18).  A wave owns the same columns of the same rows in every
     // layer, so its slice of the residual stream x stays in registers (packed f16) from layer to layer; only relu(x)
     // -- the next GEMM's input -- goes through LDS.
+    // a wave's 64 output features are exactly one k block of the next layer: it can start on it before the layer barrier
+#ifdef BL_MLP_NO_OWN_FIRST
+    const bool own = false;
+#else
+    const bool own = PASSES == 1 && NT == 2 && WAVES * 64 == W;
+#endif
     uint2 xreg[PASSES][NT][4];
 #pragma unroll
     for (int ps = 0; ps < PASSES; ps++) for (int t = 0; t < NT; t++) for (int g = 0; g < 4; g++) xreg[ps][t][g] = make_uint2(0, 0);
@@ -300,11 +311,11 @@ __global__ void __launch_bounds__(WAVES * 64) mlp_kernel(Params p, FinArgs f) {
             uint2 biasr[NT][4];                                       // issued now, needed after the GEMM
 #pragma unroll
             for (int t = 0; t < NT; t++) for (int g = 0; g < 4; g++) biasr[t][g] = *(const uint2*)(bl + n0 + 32 * t + 8 * g + 4 * hf);
-            gemm_run<NT>(rg, Rin, ld, Wl, Kl, tile0, NT, acc);
+            gemm_run<NT>(rg, Rin, ld, Wl, Kl, tile0, NT, acc, (own && l > 0) ? wave : 0, own && l > 0);
             CLK(2 + 3 * l)
             // next weights in flight before the epilogue: this layer's next pass, or the next layer's first pass
             if (ps + 1 < PASSES) gemm_prefetch<NT>(rg, Wl, Kl, tile0 + NT, NT);
-            else if (l < p.D) gemm_prefetch<NT>(rg, p.wb + (long)l * W * W, W, wave * PASSES * NT, NT);
+            else if (l < p.D) gemm_prefetch<NT>(rg, p.wb + (long)l * W * W, W, wave * PASSES * NT, NT, own ? wave : 0);
 #pragma unroll
             for (int t = 0; t < NT; t++) {
 #pragma unroll
@@ -319,7 +330,7 @@ __global__ void __launch_bounds__(WAVES * 64) mlp_kernel(Params p, FinArgs f) {
             }
         }
         CLK(3 + 3 * l)
-        __syncthreads();
+        if (!(own && l < p.D)) __syncthreads();          // else the barrier sits inside the next layer's GEMM, after its first block
         CLK(4 + 3 * l)
         if (FINISH && l == (p.D >= 1 ? 1 : 0)) {
             // the paths requested after the staging have landed by now; what they point at has the remaining layers to arrive
