@@ -385,7 +385,7 @@ __global__ void __launch_bounds__(WAVES * 64) mlp_kernel(Params p, FinArgs f) {
                 }
             }
         }
-        __syncthreads();
+        // no barrier here: Part lies in R(1), which nobody has read since the last layer's barrier (the heads read the neck in R(0))
         if (active && khalf == 1) {
 #pragma unroll
             for (int i = 0; i < 16; i++) Part[(t0 * 16 + i) * 64 + lane] = hacc[i];
