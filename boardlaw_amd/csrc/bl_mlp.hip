@@ -10,6 +10,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
+#include <type_traits>
 #include "../../include/boardlaw_amd.h"
 
 namespace blmlp {
@@ -105,7 +106,7 @@ __device__ __forceinline__ float readlane_f(float v, int lane) {
 // so each of a wave's B-fragment loads is one perfectly coalesced 1 KiB read, and the four MFMAs of a 64-wide k block
 // consume pieces s = 0..3.  (Row-major weights made every load instruction touch 32 cache lines: 97 us per forward.)
 // A fragments use the same k assignment from LDS.  K % 64 == 0.
-template <int NT> struct Ring { half8 b0[NT][4], b1[NT][4], b2[NT][4]; };
+template <int NT, int RD> struct Ring { half8 b[RD][NT][4]; };      // RD k blocks of weight fragments: RD - 1 in flight, one in use
 
 template <int NT>
 __device__ __forceinline__ void ring_load(half8 (&b)[NT][4], const uint16_t* Wp, int KB, int tile0, int ntiles_valid, int kb) {
@@ -118,25 +119,31 @@ __device__ __forceinline__ void ring_load(half8 (&b)[NT][4], const uint16_t* Wp,
     }
 }
 
-// Starts a layer's weight stream (k blocks 0 and 1).  Called BEFORE the previous layer's epilogue and barriers: weights
-// do not depend on activations, so their L2 latency hides behind that work.
-template <int NT>
-__device__ __forceinline__ void gemm_prefetch(Ring<NT>& rg, const uint16_t* Wp, int K, int tile0, int ntiles_valid, int rot = 0) {
+// Starts a layer's weight stream (its first RD - 1 k blocks).  Called BEFORE the previous layer's epilogue and barriers:
+// weights do not depend on activations, so their L2 latency hides behind that work.
+template <int NT, int RD>
+__device__ __forceinline__ void gemm_prefetch(Ring<NT, RD>& rg, const uint16_t* Wp, int K, int tile0, int ntiles_valid, int rot = 0) {
     const int KB = K >> 6;
-    ring_load<NT>(rg.b0, Wp, KB, tile0, ntiles_valid, rot);
-    if (KB > 1) ring_load<NT>(rg.b1, Wp, KB, tile0, ntiles_valid, rot + 1 < KB ? rot + 1 : rot + 1 - KB);
+#pragma unroll
+    for (int d = 0; d < RD - 1; d++)
+        if (d == 0 || d < KB) ring_load<NT>(rg.b[d], Wp, KB, tile0, ntiles_valid, rot + d < KB ? rot + d : rot + d - KB);      // KB >= 1
 }
 
-// Runs the layer: three k blocks of weight fragments in flight (their L2 latency, 1-2k cycles under load, is several
-// blocks of MFMA work and a wave has only one partner on its SIMD to hide behind).
+// Runs the layer with RD - 1 k blocks of weight fragments in flight beside the one in use.  A wave's request rate is
+// (blocks in flight) / (L2 latency, 2-2.5k cycles under load): with two in flight the eight waves pull 43 B/clk through the
+// CU's L1, with three its 64 B/clk -- so the 512-wide kernel, which has the registers, runs RD = 4.
 // `rot`: the k blocks are taken in the order rot, rot+1, ... (mod KB).  With `own_first` the wave's first block is the one it
 // wrote itself in the previous layer's epilogue (its 64 output features ARE k block `wave` of this layer when W = 512), so
 // it is consumed BEFORE the layer barrier, which then hides behind 1/8 of the GEMM instead of standing in front of it.
-template <int NT>
-__device__ __forceinline__ void gemm_run(Ring<NT>& rg, const uint16_t* in, int ldin, const uint16_t* Wp, int K, int tile0,
+// KBC > 0: K / 64 known at compile time -- the block loop is then straight-line code.  That matters more than it looks: behind
+// the branches of the run-time loop the compiler's s_waitcnt insertion loses count and waits with vmcnt(0) both before
+// each block's last MFMA and before re-using a ring buffer, i.e. it drains the weight stream once per block; in straight-line
+// code it waits for exactly the fragment an MFMA needs (vmcnt(16 + 7), ...) and the blocks in flight stay in flight.
+template <int NT, int RD, int KBC = 0, bool OWN = false>
+__device__ __forceinline__ void gemm_run(Ring<NT, RD>& rg, const uint16_t* in, int ldin, const uint16_t* Wp, int K, int tile0,
                                          int ntiles_valid, float16v (&acc)[NT], int rot = 0, bool own_first = false) {
     const int lane = threadIdx.x & 63, r = lane & 31, hf = lane >> 5;
-    const int KB = K >> 6;
+    const int KB = KBC > 0 ? KBC : K >> 6;
 #pragma unroll
     for (int t = 0; t < NT; t++) for (int i = 0; i < 16; i++) acc[t][i] = 0.f;
     const uint16_t* arow = in + r * ldin + 32 * hf;
@@ -151,17 +158,26 @@ __device__ __forceinline__ void gemm_run(Ring<NT>& rg, const uint16_t* in, int l
             for (int t = 0; t < NT; t++) if (t < ntiles_valid) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b[t][s], a[s], acc[t], 0, 0, 0);
         }
     };
-    for (int i = 0; i < KB; i += 3) {
-        if (i + 2 < KB) ring_load<NT>(rg.b2, Wp, KB, tile0, ntiles_valid, blk(i + 2));
-        compute(rg.b0, blk(i));
-        if (i == 0 && own_first) __syncthreads();
-        if (i + 1 < KB) {
-            if (i + 3 < KB) ring_load<NT>(rg.b0, Wp, KB, tile0, ntiles_valid, blk(i + 3));
-            compute(rg.b1, blk(i + 1));
+    if constexpr (KBC > 0) {
+#pragma unroll
+        for (int i = 0; i < KBC; i++) {
+            // (sched_barrier: left to itself the scheduler sinks each load to just before its use to save registers, which
+            // is the opposite of a prefetch)
+            if (i + RD - 1 < KBC) ring_load<NT>(rg.b[(i + RD - 1) % RD], Wp, KBC, tile0, NT, blk(i + RD - 1));
+            __builtin_amdgcn_sched_barrier(0);
+            compute(rg.b[i % RD], blk(i));
+            __builtin_amdgcn_sched_barrier(0);
+            if (i == 0 && OWN) __syncthreads();
         }
-        if (i + 2 < KB) {
-            if (i + 4 < KB) ring_load<NT>(rg.b1, Wp, KB, tile0, ntiles_valid, blk(i + 4));
-            compute(rg.b2, blk(i + 2));
+    } else
+    for (int i = 0; i < KB; i += RD) {
+#pragma unroll
+        for (int d = 0; d < RD; d++) {
+            if (i + d < KB) {
+                if (i + d + RD - 1 < KB) ring_load<NT>(rg.b[(d + RD - 1) % RD], Wp, KB, tile0, ntiles_valid, blk(i + d + RD - 1));
+                compute(rg.b[d], blk(i + d));
+                if (i == 0 && d == 0 && own_first) __syncthreads();
+            }
         }
     }
 }
@@ -190,7 +206,7 @@ __device__ __forceinline__ void rezero4(const float* acc4, uint2 bias, uint2 xol
 
 // WAVES x PASSES x NT x 32 == W: every wave owns PASSES groups of NT 32-column tiles of a body layer's output and works
 // through them one group at a time (accumulators and weight ring sized for NT tiles; W = 1024 would not fit otherwise).
-template <int NT, int PASSES, int WAVES, bool FINISH>
+template <int NT, int PASSES, int WAVES, bool FINISH, int RD>
 __global__ void __launch_bounds__(WAVES * 64) mlp_kernel(Params p, FinArgs f) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int W = p.W, ld = W + 8;                  // +8 halves: rows 16 B apart in bank space, ds_read_b128 conflict-free
@@ -219,11 +235,16 @@ __global__ void __launch_bounds__(WAVES * 64) mlp_kernel(Params p, FinArgs f) {
     // retires in order): lane j holds the j-th node of the env's recorded descent (bl_sim_expand's path) and,
     // separately, node slot `lane` of the env (T <= 64) for the q range.
     constexpr int EPW = 4;
-    int fb[EPW], fleaf[EPW], fmover[EPW], flen[EPW], fnode[EPW], fvalid[EPW][2];
+    // Held across the GEMMs, where registers are scarce (ring 96 + accumulators 32 + x 16 + ...): the per-env scalars are wave
+    // uniform (SGPRs), and the four envs' valid bits share one register.
+    int fb[EPW], fleaf[EPW], fmover[EPW], flen[EPW];
+    int fnode[EPW];                               // lane j's node of env e's path (left untouched until after the last GEMM:
+                                                  // any use would wait for the load, and with it for the weights in flight)
+    uint32_t fvbits = 0;                          // bit 2e + k: valid[lane + 64 k] of env e
     int fterm[EPW], fn[EPW], fallN[EPW];
     uint32_t frew[EPW], fw[EPW], fallW[EPW];
     float16v acc[NT];
-    Ring<NT> rg;
+    Ring<NT, RD> rg;
     // stage the observation tile as 32-bit words (K0 is even: 2 planes per cell), zero-padding K0 -> K0pad and rows >= M.
     // The observation loads are issued BEFORE the first weight fragments: vmcnt retires in order, so the other way round
     // the staging barrier would also wait for the (cold, just evicted by the search kernel) weights.
@@ -246,7 +267,7 @@ __global__ void __launch_bounds__(WAVES * 64) mlp_kernel(Params p, FinArgs f) {
                 }
             }
             CLK(50)
-            gemm_prefetch<NT>(rg, p.w0, p.K0pad, wave * PASSES * NT, NT);
+            gemm_prefetch<NT, RD>(rg, p.w0, p.K0pad, wave * PASSES * NT, NT);
             CLK(51)
 #pragma unroll
             for (int i = 0; i < RPT; i++) {
@@ -255,7 +276,7 @@ __global__ void __launch_bounds__(WAVES * 64) mlp_kernel(Params p, FinArgs f) {
                 for (int k = 0; k < WMAX; k++) { const int w = c + 32 * k; if (w < wpr) dst[r * (ld >> 1) + w] = st[i][k]; }
             }
         } else {
-            gemm_prefetch<NT>(rg, p.w0, p.K0pad, wave * PASSES * NT, NT);
+            gemm_prefetch<NT, RD>(rg, p.w0, p.K0pad, wave * PASSES * NT, NT);
             for (int r = r_first; r < 32; r += NTHREADS / 32)
                 for (int w = c; w < wpr; w += 32)
                     dst[r * (ld >> 1) + w] = (w < wvalid && grow(r) < p.M) ? src[(long)grow(r) * wvalid + w] : 0u;
@@ -265,11 +286,15 @@ __global__ void __launch_bounds__(WAVES * 64) mlp_kernel(Params p, FinArgs f) {
     __syncthreads();
     CLK(53)
     if constexpr (FINISH) {
+        int zero;
+        asm volatile("v_mov_b32 %0, 0" : "=v"(zero));
 #pragma unroll
         for (int e = 0; e < EPW; e++) {
             const int b = grow(EPW * wave + e);
             fb[e] = b < p.M ? b : -1;
-            const long bb = b < p.M ? b : 0;
+            // `zero` is a VGPR the compiler cannot see through: with a provably uniform address it would move each loaded value
+            // to an SGPR at once, and the s_waitcnt for that also waits for the cold weight fragments requested before
+            const long bb = (b < p.M ? b : 0) + zero;
             fleaf[e] = f.leaves[bb]; fmover[e] = f.leaf_seats[bb];
             const int16_t* path = f.path + bb * (f.T + 2);
             flen[e] = path[0];
@@ -279,8 +304,8 @@ __global__ void __launch_bounds__(WAVES * 64) mlp_kernel(Params p, FinArgs f) {
             // Loading f.valid here instead cost 4.5k cycles: the compiler tests the byte at once, and the s_waitcnt vmcnt(0)
             // it needs for that also waits for the cold weight fragments requested just before.
             const uint32_t* stg = (const uint32_t*)(R0 + 32 * ld * par0) + (EPW * wave + e) * (ld >> 1);
-            fvalid[e][0] = lane < f.A ? (int)(stg[lane] == 0u) : 0;
-            fvalid[e][1] = lane + 64 < f.A ? (int)(stg[lane + 64] == 0u) : 0;
+            if (lane < f.A && stg[lane] == 0u) fvbits |= 1u << (2 * e);
+            if (lane + 64 < f.A && stg[lane + 64] == 0u) fvbits |= 2u << (2 * e);
         }
     }
     CLK(1)
@@ -290,19 +315,45 @@ __global__ void __launch_bounds__(WAVES * 64) mlp_kernel(Params p, FinArgs f) {
     // -- the next GEMM's input -- goes through LDS.
     // a wave's 64 output features are exactly one k block of the next layer: it can start on it before the layer barrier
 #ifdef BL_MLP_NO_OWN_FIRST
-    const bool own = false;
+    constexpr bool OWNC = false;
 #else
-    const bool own = PASSES == 1 && NT == 2 && WAVES * 64 == W;
+    constexpr bool OWNC = PASSES == 1 && NT == 2;                // then WAVES * 64 == W
 #endif
+    const bool own = OWNC;
+    // heads' Linears on the un-rectified neck.  The NHpad/32 output tiles are few (3 for 9x9), so each tile's K range is split
+    // over two waves (2t: the even k blocks, 2t+1: the odd ones); the odd wave's partial sums go through LDS (R(1) is free
+    // by then) to the even one, which adds them in a fixed order and stores.  Wave w's set contains k block w -- the 64
+    // features it wrote itself in the last layer -- so with `own` it starts there, like the layers do, ahead of the barrier.
+    const int htiles = p.NHpad / 32, KBh = W >> 6, nbh = KBh >> 1;
+    auto hblk = [&](int j) {                                      // j-th k block of this wave's unit
+        const int j0 = own ? (wave >> 1) : 0;
+        const int jj = j0 + j < nbh ? j0 + j : j0 + j - nbh;
+        return (wave & 1) + 2 * jj;
+    };
+    auto heads_prefetch = [&](half8 (&be)[4], half8 (&bo)[4]) {
+        if (wave < 2 * htiles) {
+            const uint16_t* bt = p.wh + (long)(wave >> 1) * KBh * 2048 + lane * 8;
+#pragma unroll
+            for (int s2 = 0; s2 < 4; s2++) be[s2] = *(const half8*)(bt + hblk(0) * 2048 + s2 * 512);
+            if (nbh > 1) {
+#pragma unroll
+                for (int s2 = 0; s2 < 4; s2++) bo[s2] = *(const half8*)(bt + hblk(1) * 2048 + s2 * 512);
+            }
+        }
+    };
     uint2 xreg[PASSES][NT][4];
 #pragma unroll
     for (int ps = 0; ps < PASSES; ps++) for (int t = 0; t < NT; t++) for (int g = 0; g < 4; g++) xreg[ps][t][g] = make_uint2(0, 0);
-    for (int l = 0; l <= p.D; l++) {
+    auto layer = [&](const int l, auto first_c, auto last_c) __attribute__((always_inline)) {
+        constexpr bool FIRST = decltype(first_c)::value, LAST = decltype(last_c)::value;
+        constexpr int WC = WAVES * PASSES * NT * 32;                  // == W (mlp_launch picks the instantiation by it)
         const uint16_t* Wl = l == 0 ? p.w0 : p.wb + (long)(l - 1) * W * W;
         const uint16_t* bl = l == 0 ? p.b0 : p.bb + (long)(l - 1) * W;
         const int Kl = l == 0 ? p.K0pad : W;
         half2v al2 = {(f16)0.f, (f16)0.f};
-        if (l > 0) { const f16 a = (f16)p.alphas[l - 1]; al2[0] = a; al2[1] = a; }   // torch casts the f32 0-dim parameter to f16
+        // (read through the scalar cache: as a vector load its s_waitcnt vmcnt(0) at the top of every layer also waited for the
+        // whole weight prefetch instead of its first block)
+        if (l > 0) { const f16 a = (f16)((const __attribute__((address_space(4))) float*)p.alphas)[l - 1]; al2[0] = a; al2[1] = a; }   // torch casts the f32 0-dim parameter to f16
         const uint16_t* Rin = R0 + 32 * ld * ((l + par0) & 1);
         uint16_t* Rn = R0 + 32 * ld * ((l + 1 + par0) & 1);
 #pragma unroll
@@ -311,11 +362,33 @@ __global__ void __launch_bounds__(WAVES * 64) mlp_kernel(Params p, FinArgs f) {
             uint2 biasr[NT][4];                                       // issued now, needed after the GEMM
 #pragma unroll
             for (int t = 0; t < NT; t++) for (int g = 0; g < 4; g++) biasr[t][g] = *(const uint2*)(bl + n0 + 32 * t + 8 * g + 4 * hf);
-            gemm_run<NT>(rg, Rin, ld, Wl, Kl, tile0, NT, acc, (own && l > 0) ? wave : 0, own && l > 0);
+#ifdef BL_MLP_UNROLL
+            if constexpr (FIRST) gemm_run<NT, RD>(rg, Rin, ld, Wl, Kl, tile0, NT, acc);
+            else gemm_run<NT, RD, WC / 64, OWNC>(rg, Rin, ld, Wl, Kl, tile0, NT, acc, own ? wave : 0);
+#else
+            gemm_run<NT, RD>(rg, Rin, ld, Wl, Kl, tile0, NT, acc, (own && l > 0) ? wave : 0, own && l > 0);
+#endif
             CLK(2 + 3 * l)
+            if constexpr (FINISH && LAST) {
+                // what the finish step reads from the tree (the paths requested after the staging have long landed) is requested
+                // here, after the last GEMM: the last epilogue and the heads hide the trip, and the GEMMs above do not carry
+                // these 24 registers
+#pragma unroll
+                for (int e = 0; e < EPW; e++) {
+                    const long envbase = (long)(fb[e] < 0 ? 0 : fb[e]) * f.T;
+                    flen[e] = __builtin_amdgcn_readfirstlane(flen[e]);
+                    const bool in = lane < flen[e];
+                    const long i = envbase + (in ? fnode[e] : 0);
+                    fterm[e] = f.terminal[i]; fn[e] = f.n[i];
+                    frew[e] = *(const uint32_t*)(f.rewards + i * 2); fw[e] = *(const uint32_t*)(f.w + i * 2);
+                    const long t = envbase + (lane < f.T ? lane : 0);
+                    fallW[e] = *(const uint32_t*)(f.w + t * 2); fallN[e] = f.n[t];
+                }
+            }
             // next weights in flight before the epilogue: this layer's next pass, or the next layer's first pass
-            if (ps + 1 < PASSES) gemm_prefetch<NT>(rg, Wl, Kl, tile0 + NT, NT);
-            else if (l < p.D) gemm_prefetch<NT>(rg, p.wb + (long)l * W * W, W, wave * PASSES * NT, NT, own ? wave : 0);
+            if (ps + 1 < PASSES) gemm_prefetch<NT, RD>(rg, Wl, Kl, tile0 + NT, NT);
+            else if constexpr (!LAST) gemm_prefetch<NT, RD>(rg, p.wb + (long)l * W * W, W, wave * PASSES * NT, NT, own ? wave : 0);
+            else heads_prefetch(rg.b[0][0], rg.b[1][0]);        // the heads' first two k blocks travel under the last epilogue
 #pragma unroll
             for (int t = 0; t < NT; t++) {
 #pragma unroll
@@ -325,63 +398,63 @@ __global__ void __launch_bounds__(WAVES * 64) mlp_kernel(Params p, FinArgs f) {
                     uint2 xo, ro;
                     rezero4(a4, biasr[t][g], xreg[ps][t][g], al2, l == 0, xo, ro);
                     xreg[ps][t][g] = xo;
-                    *(uint2*)(Rn + brow * ld + f0) = (l == p.D) ? xo : ro;    // the heads read the neck itself
+                    *(uint2*)(Rn + brow * ld + f0) = LAST ? xo : ro;    // the heads read the neck itself
                 }
             }
         }
         CLK(3 + 3 * l)
-        if (!(own && l < p.D)) __syncthreads();          // else the barrier sits inside the next layer's GEMM, after its first block
+        if (!own) __syncthreads();                       // else the barrier sits inside the next layer's GEMM (or the heads'), after its first block
         CLK(4 + 3 * l)
-        if (FINISH && l == (p.D >= 1 ? 1 : 0)) {
-            // the paths requested after the staging have landed by now; what they point at has the remaining layers to arrive
-#pragma unroll
-            for (int e = 0; e < EPW; e++) {
-                const long envbase = (long)(fb[e] < 0 ? 0 : fb[e]) * f.T;
-                flen[e] = __builtin_amdgcn_readfirstlane(flen[e]);
-                const bool in = lane < flen[e];
-                const long i = envbase + (in ? fnode[e] : 0);
-                fterm[e] = f.terminal[i]; fn[e] = f.n[i];
-                frew[e] = *(const uint32_t*)(f.rewards + i * 2); fw[e] = *(const uint32_t*)(f.w + i * 2);
-                const long t = envbase + (lane < f.T ? lane : 0);
-                fallW[e] = *(const uint32_t*)(f.w + t * 2); fallN[e] = f.n[t];
-            }
-        }
+    };
+    // the last layer is its own copy of the body: it prefetches the heads' weights instead of a next layer's (one loop body
+    // doing either keeps both sets of registers alive around the back edge)
+#ifdef BL_MLP_UNROLL
+    if (p.D == 0) layer(0, std::true_type{}, std::true_type{});
+    else {
+        layer(0, std::true_type{}, std::false_type{});
+        for (int l = 1; l < p.D; l++) layer(l, std::false_type{}, std::false_type{});
+        layer(p.D, std::false_type{}, std::true_type{});
     }
+#else
+    for (int l = 0; l < p.D; l++) layer(l, std::false_type{}, std::false_type{});
+    layer(p.D, std::false_type{}, std::true_type{});
+#endif
     const uint16_t* X = R0;                                        // the neck (par0 makes the last layer write R(0))
-    // heads' Linears on the un-rectified neck.  The NHpad/32 output tiles are few (3 for 9x9), so each tile's K range is
-    // split over two waves (waves 2t and 2t+1); the upper half's partial sums go through LDS (R(1) is free now) to the
-    // lower half's wave, which adds them in a fixed order and stores.
-    const int htiles = p.NHpad / 32, KBh = W >> 6;
     float* Part = (float*)(R0 + 32 * ld);                         // [unit][16][64] f32, 4 KiB per unit
     for (int round = 0; round * WAVES < 2 * htiles; round++) {    // same trip count for every wave: uniform barriers
         const int u = round * WAVES + wave;
         const bool active = u < 2 * htiles;
         const int t0 = active ? (u >> 1) : 0, khalf = u & 1;
-        const int kb0 = khalf ? KBh / 2 : 0, kb1 = khalf ? KBh : KBh / 2;
+        const bool first = round == 0;                            // round 0's first two blocks are in flight already
         float16v hacc;
         for (int i = 0; i < 16; i++) hacc[i] = 0.f;
+        const uint16_t* arow = X + brow * ld + 32 * hf;
+        const uint16_t* bt = p.wh + (long)t0 * KBh * 2048 + lane * 8;
+        auto loadb = [&](half8 (&b)[4], int kb) {
+#pragma unroll
+            for (int s2 = 0; s2 < 4; s2++) b[s2] = *(const half8*)(bt + kb * 2048 + s2 * 512);
+        };
+        auto step = [&](half8 (&b)[4], int kb) {
+            half8 a[4];
+#pragma unroll
+            for (int s2 = 0; s2 < 4; s2++) a[s2] = *(const half8*)(arow + kb * 64 + 8 * s2);
+#pragma unroll
+            for (int s2 = 0; s2 < 4; s2++) hacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(b[s2], a[s2], hacc, 0, 0, 0);
+        };
+        half8 (&be)[4] = rg.b[0][0], (&bo)[4] = rg.b[1][0];           // two k blocks in flight, alternating (the layers' ring is free)
         if (active) {
-            const uint16_t* arow = X + brow * ld + 32 * hf;
-            const uint16_t* bt = p.wh + (long)t0 * KBh * 2048 + lane * 8;
-            auto loadb = [&](half8 (&b)[4], int kb) {
-#pragma unroll
-                for (int s2 = 0; s2 < 4; s2++) b[s2] = *(const half8*)(bt + kb * 2048 + s2 * 512);
-            };
-            auto step = [&](half8 (&b)[4], int kb) {
-                half8 a[4];
-#pragma unroll
-                for (int s2 = 0; s2 < 4; s2++) a[s2] = *(const half8*)(arow + kb * 64 + 8 * s2);
-#pragma unroll
-                for (int s2 = 0; s2 < 4; s2++) hacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(b[s2], a[s2], hacc, 0, 0, 0);
-            };
-            half8 be[4], bo[4];                                   // two k blocks in flight, alternating
-            loadb(be, kb0);
-            for (int kb = kb0; kb < kb1; kb += 2) {
-                if (kb + 1 < kb1) loadb(bo, kb + 1);
-                step(be, kb);
-                if (kb + 1 < kb1) {
-                    if (kb + 2 < kb1) loadb(be, kb + 2);
-                    step(bo, kb + 1);
+            if (!first) { loadb(be, hblk(0)); if (nbh > 1) loadb(bo, hblk(1)); }
+            step(be, hblk(0));
+            if (2 < nbh) loadb(be, hblk(2));
+        }
+        if (first && own) __syncthreads();                        // the last layer's barrier, behind the wave's own block
+        if (active) {
+            for (int j = 1; j < nbh; j += 2) {
+                step(bo, hblk(j));
+                if (j + 2 < nbh) loadb(bo, hblk(j + 2));
+                if (j + 1 < nbh) {
+                    step(be, hblk(j + 1));
+                    if (j + 3 < nbh) loadb(be, hblk(j + 3));
                 }
             }
         }
@@ -431,8 +504,8 @@ __global__ void __launch_bounds__(WAVES * 64) mlp_kernel(Params p, FinArgs f) {
             leaf[e] = __builtin_amdgcn_readfirstlane(fleaf[e]);
             ev[e][0] = -INFINITY; ev[e][1] = -INFINITY;
             if (lane < Wsm) {
-                if (lane < A) ev[e][0] = fvalid[e][0] ? h2f(Out[r * p.NHpad + lane]) : -INFINITY;
-                if (two && lane + Wsm < A) ev[e][1] = fvalid[e][1] ? h2f(Out[r * p.NHpad + lane + Wsm]) : -INFINITY;
+                if (lane < A) ev[e][0] = ((fvbits >> (2 * e)) & 1u) ? h2f(Out[r * p.NHpad + lane]) : -INFINITY;
+                if (two && lane + Wsm < A) ev[e][1] = ((fvbits >> (2 * e + 1)) & 1u) ? h2f(Out[r * p.NHpad + lane + Wsm]) : -INFINITY;
             }
             mx[e] = two ? ((ev[e][0] > ev[e][1]) ? ev[e][0] : ev[e][1]) : ev[e][0];
         }
@@ -554,12 +627,13 @@ __global__ void __launch_bounds__(WAVES * 64) mlp_kernel(Params p, FinArgs f) {
             wnew[e] = (uint32_t)f2h(w0[e]) | ((uint32_t)f2h(w1[e]) << 16);
             nnew[e] = (int)(int16_t)(fn[e] + 2);                            // n += 1 once per seat (cuda.cu:230), int16 wrap kept
             const bool onp = lane < flen[e];
+            const int fnode_e = fnode[e];
             if (onp) {
-                const long i = envbase[e] + fnode[e];
+                const long i = envbase[e] + fnode_e;
                 *(uint32_t*)(f.w + i * 2) = wnew[e];
                 f.n[i] = (int16_t)nnew[e];
             }
-            const uint32_t lo = (onp && fnode[e] < 32) ? (1u << fnode[e]) : 0u, hi = (onp && fnode[e] >= 32) ? (1u << (fnode[e] - 32)) : 0u;
+            const uint32_t lo = (onp && fnode_e < 32) ? (1u << fnode_e) : 0u, hi = (onp && fnode_e >= 32) ? (1u << (fnode_e - 32)) : 0u;
             const uint32_t mlo = wave_or_u32(lo), mhi = wave_or_u32(hi);
             const bool replaced = ((lane < 32 ? mlo >> lane : mhi >> (lane - 32)) & 1u) != 0;
             if (fb[e] >= 0) {
@@ -607,23 +681,23 @@ static int mlp_launch(const blmlp::Params& p, const blmlp::FinArgs* fin, bl_stre
     hipStream_t hs = (hipStream_t)stream;
     const FinArgs f = fin ? *fin : FinArgs{};
     // above the 64 KiB default the limit has to be raised per kernel (gfx950 has 160 KiB per CU)
-#define BL_MLP_LAUNCH1(NT, PASSES, WAVES, FIN)                                                                         \
+#define BL_MLP_LAUNCH1(NT, PASSES, WAVES, FIN, RD)                                                                         \
     {                                                                                                                  \
         static size_t raised = 65536;                                                                                  \
         if (lds > raised) {                                                                                            \
-            if (hipFuncSetAttribute((const void*)mlp_kernel<NT, PASSES, WAVES, FIN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return BL_ELAUNCH; \
+            if (hipFuncSetAttribute((const void*)mlp_kernel<NT, PASSES, WAVES, FIN, RD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return BL_ELAUNCH; \
             raised = lds;                                                                                              \
         }                                                                                                              \
-        hipLaunchKernelGGL((mlp_kernel<NT, PASSES, WAVES, FIN>), grid, dim3(WAVES * 64), lds, hs, p, f);               \
+        hipLaunchKernelGGL((mlp_kernel<NT, PASSES, WAVES, FIN, RD>), grid, dim3(WAVES * 64), lds, hs, p, f);               \
     }
-#define BL_MLP_LAUNCH(NT, PASSES, WAVES) { if (fin) BL_MLP_LAUNCH1(NT, PASSES, WAVES, true) else BL_MLP_LAUNCH1(NT, PASSES, WAVES, false) }
+#define BL_MLP_LAUNCH(NT, PASSES, WAVES, RD) { if (fin) BL_MLP_LAUNCH1(NT, PASSES, WAVES, true, RD) else BL_MLP_LAUNCH1(NT, PASSES, WAVES, false, RD) }
     // 8 waves (two per SIMD) from W = 256 up: while one wave waits for its weight fragments the other issues MFMAs
     switch (W / 128) {
-        case 1: if (fin) return BL_ETOOBIG; BL_MLP_LAUNCH1(1, 1, 4, false) break;      // the epilogue assumes 8 waves
-        case 2: BL_MLP_LAUNCH(1, 1, 8) break;
-        case 4: BL_MLP_LAUNCH(2, 1, 8) break;
-        case 6: BL_MLP_LAUNCH(1, 3, 8) break;
-        case 8: BL_MLP_LAUNCH(2, 2, 8) break;
+        case 1: if (fin) return BL_ETOOBIG; BL_MLP_LAUNCH1(1, 1, 4, false, 3) break;      // the epilogue assumes 8 waves
+        case 2: BL_MLP_LAUNCH(1, 1, 8, 3) break;
+        case 4: BL_MLP_LAUNCH(2, 1, 8, 3) break;
+        case 6: BL_MLP_LAUNCH(1, 3, 8, 3) break;
+        case 8: BL_MLP_LAUNCH(2, 2, 8, 3) break;
         default: return BL_ETOOBIG;
     }
 #undef BL_MLP_LAUNCH
