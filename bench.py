@@ -324,7 +324,8 @@ def main():
                                    + '; step = one self-play move of the batch',
                        'envs_per_gpu': args.envs, 'nodes': NODES, 'boardsize': BOARD, 'parallelism': f'replicas x{world}', 'launch': launch,
                        'network': ('nn.Module under fp16 autocast' if args.plain_network else 'fp16 inference plan, torch GEMMs (bit-identical to autocast)'
-                                   if (args.torch_gemms or not agent.network.prefers_fused(args.envs))
+                                   if args.torch_gemms
+                                   else 'a launch per Linear, bl_mlp_layers_f16 (autocast rounding points), + bl_sim_finish' if not agent.network.prefers_fused(args.envs)
                                    else 'fused MFMA kernel bl_sim_infer_finish (autocast rounding points; <= 1 f16 ulp vs autocast)') + '; root evaluation fp32',
                        'rng': 'MoveRng: torch generator, the T-1 descend uniforms of a move drawn as ONE (T-1,B,T) f16 block instead of T-1 rand_like calls',
                        'value_reference_rng_protocol': value_torch_rng,

@@ -41,6 +41,7 @@ SYMBOLS = {
     'bl_sim_finish': (_i, [ctypes.POINTER(Search), _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     'bl_rezero_relu_f16': (_i, [_vp, _vp, _vp, _vp, _vp, ctypes.c_long, _vp]),
     'bl_mlp_forward_f16': (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
+    'bl_mlp_layers_f16': (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     'bl_root_mlp_f32': (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     'bl_sim_infer_finish': (_i, [ctypes.POINTER(Search), _i] + [_vp] * 11 + [_i] * 4 + [_vp]),
     'bl_sim_root': (_i, [ctypes.POINTER(Search), _i, _vp, _vp, _vp, _vp]),

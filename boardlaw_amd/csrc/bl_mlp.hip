@@ -663,6 +663,116 @@ __global__ void __launch_bounds__(WAVES * 64) mlp_kernel(Params p, FinArgs f) {
     CLK(40)
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------
+// One Linear (+ ReZero tail) per launch, every layer split over the whole chip: the plan for networks whose weights are too
+// many to stream through each workgroup's L1 (mlp_kernel's time is 2 * weights bytes / 64 B/clk per 32-row workgroup: 1024x8 is
+// 17.9 MB = 130 us however small the batch), i.e. wide networks on small batches -- 13x13 / 1024 envs / 1024x8 (BASELINE
+// config 4's per-GPU shape).  A workgroup of 4 waves takes 32 rows x 128 output features: the input rows (relu applied on the
+// way in, as the next block's relu) are staged in LDS once, every wave streams the fragment-major weights of its 32 features
+// (the same packing as above) into v_mfma_f32_32x32x16_f16, and the epilogue is the fused kernel's (rezero4: torch's
+// rounding points).  The residual stream x lives in global memory between launches (two buffers, ping-pong: a workgroup
+// writes features other workgroups still read as inputs).  Per launch a CU moves 64 KiB of activations + 256 KiB of weights
+// instead of the whole network.
+// ------------------------------------------------------------------------------------------------------------------
+struct LayerArgs {
+    const uint16_t* X; int ldx, Kvalid, Kpad; int relu_in;        // input rows (M, Kvalid) f16, row stride ldx; zero padded to Kpad
+    const uint16_t* Wp; const uint16_t* bias; int N;              // packed (N/32 tiles x Kpad/64 blocks), bias (N); N % 32 == 0
+    const uint16_t* Xres; const float* alpha;                     // residual rows (M, N) stride N and its ReZero alpha, or null: y itself
+    uint16_t* Y; int ldy;                                         // body: x' (M, N)
+    uint16_t* policy; uint16_t* value; int NH;                    // heads (Y == null): features 0..NH-2 -> policy (M, NH-1), NH-1 -> value (M)
+    int M;
+};
+
+// RD - 1 k blocks of 4 KiB in flight per wave; KBC = Kpad / 64 when it is one of the body widths' (the block loop is then
+// straight-line code and every MFMA waits for exactly its fragment -- with ONE wave per SIMD there is nobody to hide a
+// drained weight stream behind, unlike in mlp_kernel), 0 = any (the intake).
+template <int RD, int KBC>
+__global__ void __launch_bounds__(256) layer_kernel(LayerArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    uint16_t* R = (uint16_t*)smem;
+    const int ld = a.Kpad + 8;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int row0 = blockIdx.y * 32, tile = blockIdx.x * 4 + wave, ntiles = a.N >> 5;
+    const int brow = lane & 31, hf = lane >> 5;
+    Ring<1, RD> rg;
+    float16v acc[1];
+    const bool active = tile < ntiles;
+    // the input rows first, then the first weight fragments (vmcnt retires in order: see mlp_kernel)
+    const half2v z2 = {(f16)0.f, (f16)0.f};
+    if ((a.ldx & 7) == 0 && (a.Kvalid & 7) == 0) {
+        // 8 threads per row, 16 bytes each: one 128-byte line per row and step; all of a thread's chunks in flight at once
+        // (Kpad <= 1024: at most 16), the weight prefetch right behind them
+        const int r = tid >> 3, j = tid & 7;
+        const bool rok = row0 + r < a.M;
+        const uint16_t* src = a.X + (long)(row0 + r) * a.ldx + 8 * j;
+        uint16_t* dst = R + r * ld + 8 * j;
+        constexpr int NB = 16;
+        uint4 v[NB];
+#pragma unroll
+        for (int i = 0; i < NB; i++) {
+            v[i] = make_uint4(0, 0, 0, 0);
+            if (rok && 64 * i + 8 * j < a.Kvalid) v[i] = *(const uint4*)(src + 64 * i);
+        }
+        if (active) gemm_prefetch<1, RD>(rg, a.Wp, a.Kpad, tile, 1);
+#pragma unroll
+        for (int i = 0; i < NB; i++) {
+            if (64 * i < a.Kpad) {
+                uint4 w = v[i];
+                if (a.relu_in) {
+                    w.x = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(half2v, w.x), z2));
+                    w.y = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(half2v, w.y), z2));
+                    w.z = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(half2v, w.z), z2));
+                    w.w = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(half2v, w.w), z2));
+                }
+                *(uint4*)(dst + 64 * i) = w;
+            }
+        }
+    } else {
+        // rows that are only 4-byte aligned (the observation: 2 planes per cell): 32-bit words
+        if (active) gemm_prefetch<1, RD>(rg, a.Wp, a.Kpad, tile, 1);
+        const int wpr = a.Kpad >> 1, wvalid = a.Kvalid >> 1;
+        for (int c = tid; c < 32 * wpr; c += 256) {
+            const int r = c / wpr, w = c - r * wpr;
+            uint32_t v = (row0 + r < a.M && w < wvalid) ? ((const uint32_t*)a.X)[((long)(row0 + r) * a.ldx >> 1) + w] : 0u;
+            if (a.relu_in) v = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(half2v, v), z2));
+            ((uint32_t*)R)[r * (ld >> 1) + w] = v;
+        }
+    }
+    __syncthreads();
+    if (!active) return;
+    const int n0 = tile * 32;
+    uint2 biasr[4], xold[4];
+    const long grow = row0 + brow;
+    const bool rowok = grow < a.M;
+#pragma unroll
+    for (int g = 0; g < 4; g++) {
+        biasr[g] = *(const uint2*)(a.bias + n0 + 8 * g + 4 * hf);
+        xold[g] = make_uint2(0, 0);
+        if (a.Xres && rowok) xold[g] = *(const uint2*)(a.Xres + grow * a.N + n0 + 8 * g + 4 * hf);
+    }
+    half2v al2 = {(f16)0.f, (f16)0.f};
+    if (a.Xres) { const f16 al = (f16)((const __attribute__((address_space(4))) float*)a.alpha)[0]; al2[0] = al; al2[1] = al; }
+    gemm_run<1, RD, KBC, false>(rg, R, ld, a.Wp, a.Kpad, tile, 1, acc);
+    if (!rowok) return;
+#pragma unroll
+    for (int g = 0; g < 4; g++) {
+        const int f0 = n0 + 8 * g + 4 * hf;
+        const float a4[4] = {acc[0][4 * g], acc[0][4 * g + 1], acc[0][4 * g + 2], acc[0][4 * g + 3]};
+        uint2 xo, ro;
+        rezero4(a4, biasr[g], xold[g], al2, a.Xres == nullptr, xo, ro);
+        if (a.Y) *(uint2*)(a.Y + grow * a.ldy + f0) = xo;
+        else {
+            const uint16_t o[4] = {(uint16_t)xo.x, (uint16_t)(xo.x >> 16), (uint16_t)xo.y, (uint16_t)(xo.y >> 16)};
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                if (f0 + j < a.NH - 1) a.policy[grow * (a.NH - 1) + f0 + j] = o[j];
+                else if (f0 + j == a.NH - 1) a.value[grow] = o[j];
+            }
+        }
+    }
+}
+
 }  // namespace blmlp
 
 #ifdef BL_MLP_CLK
@@ -722,6 +832,52 @@ extern "C" int bl_mlp_forward_f16(const void* obs, int M, int K0, const void* w0
     Params p{(const uint16_t*)obs, (const uint16_t*)w0, (const uint16_t*)b0, (const uint16_t*)wb, (const uint16_t*)bb, alphas,
              (const uint16_t*)wh, (const uint16_t*)bh, (uint16_t*)policy_out, (uint16_t*)value_out, M, K0, K0pad, W, D, NH, NHpad, 0};
     return mlp_launch(p, nullptr, stream);
+}
+
+extern "C" int bl_mlp_layers_f16(const void* obs, int M, int K0, const void* w0, const void* b0, const void* wb,
+                                 const void* bb, const float* alphas, const void* wh, const void* bh, int W, int D,
+                                 int K0pad, int NH, int NHpad, void* scratch, void* policy_out, void* value_out, bl_stream_t stream) {
+    using namespace blmlp;
+    if (!policy_out || !value_out || !scratch) return BL_EINVAL;
+    if (int rc = mlp_check(obs, M, K0, w0, b0, wb, bb, alphas, wh, bh, W, D, K0pad, NH, NHpad)) return rc;
+    if ((K0 & 1) != 0) return BL_EINVAL;
+    hipStream_t hs = (hipStream_t)stream;
+    uint16_t* buf[2] = {(uint16_t*)scratch, (uint16_t*)scratch + (size_t)M * W};
+    const dim3 rows((M + 31) / 32);
+    int rc = BL_OK;
+    auto launch = [&](const LayerArgs& a, int Kpad) {
+        const dim3 grid((a.N / 32 + 3) / 4, rows.x);
+        const size_t l = (size_t)32 * (Kpad + 8) * 2;
+#define BL_LAYER_LAUNCH(RD, KBC)                                                                                                  \
+        {                                                                                                                         \
+            static size_t raised = 65536;                                                                                         \
+            if (l > raised) {                                                                                                     \
+                if (hipFuncSetAttribute((const void*)layer_kernel<RD, KBC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l) != hipSuccess) { rc = BL_ELAUNCH; return; } \
+                raised = l;                                                                                                       \
+            }                                                                                                                     \
+            hipLaunchKernelGGL((layer_kernel<RD, KBC>), grid, dim3(256), l, hs, a);                                               \
+        }
+        switch (Kpad) {
+            case 1024: BL_LAYER_LAUNCH(8, 16) break;
+            case 768: BL_LAYER_LAUNCH(8, 12) break;
+            case 512: BL_LAYER_LAUNCH(6, 8) break;
+            case 256: BL_LAYER_LAUNCH(4, 4) break;
+            default: BL_LAYER_LAUNCH(3, 0) break;
+        }
+#undef BL_LAYER_LAUNCH
+    };
+    // intake: x = Linear(obs)
+    launch(LayerArgs{(const uint16_t*)obs, K0, K0, K0pad, 0, (const uint16_t*)w0, (const uint16_t*)b0, W, nullptr, nullptr,
+                     buf[0], W, nullptr, nullptr, 0, M}, K0pad);
+    // ReZero blocks: x' = x + alpha * Linear(relu(x))
+    for (int l = 0; l < D; l++)
+        launch(LayerArgs{buf[l & 1], W, W, W, 1, (const uint16_t*)wb + (size_t)l * W * W, (const uint16_t*)bb + (size_t)l * W, W,
+                         buf[l & 1], alphas + l, buf[(l + 1) & 1], W, nullptr, nullptr, 0, M}, W);
+    // heads on the un-rectified neck
+    launch(LayerArgs{buf[D & 1], W, W, W, 0, (const uint16_t*)wh, (const uint16_t*)bh, NHpad, nullptr, nullptr, nullptr, 0,
+                     (uint16_t*)policy_out, (uint16_t*)value_out, NH, M}, W);
+    if (rc != BL_OK) return rc;
+    return hipGetLastError() == hipSuccess ? BL_OK : BL_ELAUNCH;
 }
 
 extern "C" int bl_sim_infer_finish(const bl_search_t* s, int sim, const int16_t* leaves, const void* obs, const uint8_t* valid,

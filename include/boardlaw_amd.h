@@ -190,6 +190,16 @@ int bl_root_mlp_f32(const float* obs /*(M,K0)*/, int M, int K0, const float* w0,
                     const float* bb, const float* alphas /*(D)*/, const float* wh, const float* bh, int W, int D, int K0pad,
                     int NH, int NHpad, float* policy_out, float* value_out, bl_stream_t stream);
 
+/* The same network as bl_mlp_forward_f16 (same packed weights, same rounding points), one launch per Linear with every layer
+ * split over the whole chip: 32 rows x 128 output features per workgroup, the ReZero tail fused into the epilogue, the residual
+ * stream kept in `scratch` (2*M*W f16, caller-owned) between launches.  The plan for wide networks on small batches, where
+ * bl_mlp_forward_f16's per-workgroup weight stream (2 bytes x all weights through one CU's L1) is the bound: 1024x8 on 1024 rows.
+ * K0 even.  Replaces, like bl_mlp_forward_f16, the reference's autocast FCModel forward (boardlaw/networks.py:10-40). */
+int bl_mlp_layers_f16(const void* obs /*f16 (M,K0)*/, int M, int K0, const void* w0, const void* b0, const void* wb,
+                      const void* bb, const float* alphas, const void* wh, const void* bh, int W, int D, int K0pad, int NH,
+                      int NHpad, void* scratch /*f16 (2,M,W)*/, void* policy_out /*f16 (M,NH-1)*/, void* value_out /*f16 (M)*/,
+                      bl_stream_t stream);
+
 /* bl_mlp_forward_f16 followed by bl_sim_finish as ONE launch: the workgroup that took 32 leaves through the network also
  * applies the heads to them, stores logits/v, backs up along the recorded paths and publishes the next q range; what
  * that step reads from the tree is requested at the start of the kernel and arrives under the GEMMs.  Same results as

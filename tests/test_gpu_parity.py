@@ -545,6 +545,38 @@ def test_fused_mlp_matches_autocast(S, width, depth, B):
     assert close > 0.99, float(close)
 
 
+@pytest.mark.parametrize('S,width,depth,B', [(13, 1024, 8, 1024), (9, 512, 4, 1000), (7, 128, 4, 33), (13, 768, 3, 200), (19, 1024, 2, 70), (6, 256, 0, 64), (11, 512, 5, 2049)])
+def test_layers_mlp_matches_autocast_and_the_fused_kernel(S, width, depth, B):
+    """bl_mlp_layers_f16 (a launch per Linear, every layer split over the chip: the plan for wide networks on small batches)
+    against the module under fp16 autocast -- tolerance as for the one-kernel plan: 3 f16 ulps of the largest activation
+    scale plus 1 % relative, >= 98 % of outputs within 1 ulp -- and against bl_mlp_forward_f16 itself (same rounding points,
+    another order of the k blocks: >= 99 % of outputs bit-identical or 1 ulp apart)."""
+    from boardlaw_amd import networks, heads
+    torch.manual_seed(S + depth)
+    net = networks.FCModel(heads.Tensor((S, S, 2)), heads.Masked(S * S), width=width, depth=depth).to(DEV)
+    with torch.no_grad():
+        for blk in list(net.body)[1:]:
+            getattr(blk, 'α').fill_(float(torch.randn(()) * 0.5))
+    class W_: pass
+    w = W_(); w.obs = (torch.rand(B, S, S, 2, device=DEV) < .3).half()
+    plan = networks.Inference(net, fused=True)
+    plan.refresh()
+    plan.FUSED_ALWAYS_BYTES = 0; plan.FUSED_MIN_TILES = 1 << 30          # never the one kernel
+    assert plan._packed is not None and not plan.prefers_fused(B)
+    with torch.no_grad(), torch.autocast('cuda'):
+        p0, v0 = net.raw(w)
+        p1, v1 = plan.raw(w)
+        plan.FUSED_MIN_TILES = 0
+        p2, v2 = plan.raw(w)
+    assert p1.shape == p0.shape and v1.shape == v0.shape and p1.dtype == torch.half
+    for a, b in ((p0.float(), p1.float()), (v0.float(), v1.float())):
+        tol = 3 * 2**-10 * a.abs().max().clamp(min=1.) + 0.01 * a.abs()
+        assert ((a - b).abs() <= tol).all(), float((a - b).abs().max())
+    for ref, least in ((p0, 0.98), (p2, 0.99)):     # (the library's own summation order: 98.5 % at 1024x8, where both kernels agree bit for bit)
+        close = ((ref.float() - p1.float()).abs() <= 2**-9 * ref.float().abs().clamp(min=2**-5)).float().mean()
+        assert close > least, float(close)
+
+
 def test_move_rng_serves_one_block_per_move():
     from boardlaw_amd import hex, networks
     from boardlaw_amd.mcts import MCTSAgent, MoveRng, mcts
