@@ -929,10 +929,12 @@ def assert_search_equals(m, want):
 
 @pytest.mark.parametrize('S,B,T,width,depth,mode', [(9, 4096, 64, 512, 4, 'eager'), (9, 4096, 64, 512, 4, 'graph'),
                                                     (13, 1024, 256, 1024, 8, 'eager'), (5, 64, 16, 256, 2, 'graph'),
-                                                    (9, 333, 64, 512, 4, 'eager-torch-gemms')])
+                                                    (9, 333, 64, 512, 4, 'eager-torch-gemms'),
+                                                    (13, 1024, 256, 1024, 8, 'graph-plan'), (9, 512, 64, 1024, 4, 'eager-plan')])
 def test_bench_launch_sequence_vs_oracle(oracle, S, B, T, width, depth, mode):
     """What bench.py times -- bl_sim_plant_root, then T-1 x (bl_sim_expand -> bl_sim_infer_finish) with the real network's
-    fused fp16 plan (13x13/256 nodes: bl_mlp_forward_f16 + bl_sim_finish, the T > 64 route), eagerly with torch's
+    fused fp16 plan (13x13/256 nodes: bl_mlp_forward_f16 + bl_sim_finish, the T > 64 route; '-plan': what the plan picks for
+    config 4's 1024x8 network on 1024 rows, bl_mlp_layers_f16 + bl_sim_finish), eagerly with torch's
     per-simulation uniforms and as a captured HIP graph with MoveRng -- replayed on the host through the oracle, which is
     handed the uniforms and the leaf evaluations the GPU stored.  Every tree array, visit count, value sum, board and the
     root distribution must be identical: BASELINE config 2 and config 4's per-GPU shape at full size."""
@@ -948,9 +950,13 @@ def test_bench_launch_sequence_vs_oracle(oracle, S, B, T, width, depth, mode):
         for p_ in net.model.parameters():
             if p_.ndim == 0:
                 p_.fill_(0.3)          # ReZero gains start at 0: make the evaluation depend on the position
-    net.FUSED_MIN_TILES = 0            # keep bl_mlp_forward_f16 on the 13x13 / 1024-row case (the plan would pick the GEMMs there)
-    net.refresh()
-    if mode == 'graph':
+    if mode.endswith('-plan'):         # the plan's own choice for a wide network on a small batch: bl_mlp_layers_f16 + bl_sim_finish
+        net.refresh()
+        assert not net.prefers_fused(B)
+    else:
+        net.FUSED_MIN_TILES = 0        # keep bl_mlp_forward_f16 on the 13x13 / 1024-row case (the plan would pick a launch per Linear there)
+        net.refresh()
+    if mode.startswith('graph'):
         rng = MoveRng()
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
@@ -1103,18 +1109,19 @@ def test_two_actors_on_two_streams_equal_the_same_calls_on_one():
 
 def test_inference_plan_selection():
     """Inference picks the one-kernel plan by what bounds it (one workgroup streams all the weights): always for 512x4,
-    for 1024x8 only when the batch fills 64 workgroups; MCTS.simulate follows (fused finish or raw() + bl_sim_finish)."""
+    for 1024x8 only when the batch fills 96 workgroups -- below that a launch per Linear (bl_mlp_layers_f16); MCTS.simulate
+    follows (fused finish or raw() + bl_sim_finish)."""
     from boardlaw_amd import hex, networks
     from boardlaw_amd.mcts import mcts
     w = hex.Hex.initial(8, 9, device=DEV)
     small = networks.Inference(networks.FCModel(w.obs_space, w.action_space, width=512, depth=4).to(DEV), fused=True); small.refresh()
     wide = networks.Inference(networks.FCModel(w.obs_space, w.action_space, width=1024, depth=8).to(DEV), fused=True); wide.refresh()
     assert small.prefers_fused(1) and small.prefers_fused(4096) and small.fused_params(8) is not None
-    assert not wide.prefers_fused(1024) and wide.prefers_fused(2048) and wide.prefers_fused(4096)
+    assert not wide.prefers_fused(1024) and not wide.prefers_fused(2048) and wide.prefers_fused(3072) and wide.prefers_fused(4096)
     assert wide.fused_params(1024) is None and wide.fused_params(4096) is not None and wide.fused_params() is not None
     assert not networks.Inference(small.model, fused=False).prefers_fused(4096)
     torch.manual_seed(0)
-    a = mcts(w, wide, n_nodes=8)                       # 8 rows of 1024x8: the GEMM plan + bl_sim_finish
+    a = mcts(w, wide, n_nodes=8)                       # 8 rows of 1024x8: a launch per Linear + bl_sim_finish
     wide.FUSED_MIN_TILES = 0
     torch.manual_seed(0)
     b = mcts(w, wide, n_nodes=8)                       # the same search through bl_sim_infer_finish
