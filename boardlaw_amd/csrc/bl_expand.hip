@@ -406,6 +406,272 @@ __global__ void __launch_bounds__(BL_WAVE * NW, (RMAX <= 3 ? 8 : 4)) sim_expand2
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// Two nodes per wave.  While every env still descends, the kernel is bound by VALU issue (4.3 k VALU instructions per env,
+// 8 waves per SIMD), and more than half of those are the folds' v_add_f32_dpp -- whose count depends on the chain length, not
+// on how many chains a step advances.  Here ONE wave per env evaluates the current node in lanes 0..31 and its guessed
+// continuation in lanes 32..63: rows 0/1 carry node A's S/g chains, rows 2/3 node B's, in blocks of 16 kept actions; a step
+// still is one `row_shr:1` instruction, now advancing four chains, and a block hands over with one `row_ror:1` (lane 15 -> lane
+// 0 of every row).  Same arithmetic per element, same order per chain: bit-identical results.  Per batch of two nodes the
+// folds cost one wave's 64 steps instead of two waves' 64 each, nothing is exchanged through LDS and no barrier is needed.
+// RB: blocks of 16 kept actions (ceil(A / 16)); T <= 64.
+// ------------------------------------------------------------------------------------------------------------------
+template <bool FAST>
+__device__ __forceinline__ void fold_ror(float& x, const float xprev, const float t) {     // lane 0 of every row <- xprev[15 of the row] + t
+    if constexpr (FAST) asm volatile("s_nop 0\n\tv_add_f32_dpp %0, %1, %2 row_ror:1 row_mask:0xf bank_mask:0x1\n\ts_nop 0\n\t" : "+v"(x) : "v"(xprev), "v"(t));
+    else asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %1, %2 row_ror:1 row_mask:0xf bank_mask:0x1\n\ts_nop 1\n\t" : "+v"(x) : "v"(xprev), "v"(t));
+}
+__device__ __forceinline__ int row_sum_i32(int v) {        // lane 15 of every row ends with the row's sum
+    v += dpp_i<0x111, 0xf>(0, v); v += dpp_i<0x112, 0xf>(0, v); v += dpp_i<0x114, 0xf>(0, v); v += dpp_i<0x118, 0xf>(0, v);
+    return v;
+}
+__device__ __forceinline__ float row_max_f32(float v) {    // lane 15 of every row ends with the row's max
+    v = fmaxf(v, dpp_f<0x111, 0xf>(v, v)); v = fmaxf(v, dpp_f<0x112, 0xf>(v, v)); v = fmaxf(v, dpp_f<0x114, 0xf>(v, v));
+    v = fmaxf(v, dpp_f<0x118, 0xf>(v, v));
+    return v;
+}
+
+template <int RB, bool FAST>
+__global__ void __launch_bounds__(BL_WAVE) sim_expand3_kernel(Search s, int sim, const uint16_t* rands, int16_t* leaves_out,
+                                                              void* obs_out, uint8_t* valid_out, int32_t* leaf_seats_out) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    uint8_t* cells = (uint8_t*)smem;
+    const int S = s.S, A = S * S, T = s.T;
+    const int lane = threadIdx.x & 63;
+    const int b = s.order ? s.order[blockIdx.x] : blockIdx.x;
+    const long envbase = (long)b * T;
+    const bool hiNode = lane >= 32;                 // which of the batch's two nodes this lane works for
+    const bool isS = !((lane >> 4) & 1);            // rows 0, 2: S chain (and prob); rows 1, 3: g chain
+    const int el = lane & 15;
+    int16_t* path = s.path ? s.path + (long)b * (T + 2) : nullptr;
+
+    // ---- the env's node slots, lane t <-> slot t (T <= 64)
+    uint32_t wp = 0; int nn = 0, info = 0, rd = 0, fav = -1;
+    if (lane < T) {
+        wp = *(const uint32_t*)(s.w + (envbase + lane) * 2);
+        nn = s.n[envbase + lane];
+        info = (int)(uint16_t)s.nk[envbase + lane] | ((s.seats[envbase + lane] & 1) << 16) | ((s.terminal[envbase + lane] ? 1 : 0) << 17);
+        rd = rands[envbase + lane];
+        fav = s.fav[envbase + lane];
+    }
+    float lo, hi;
+    load_qrange(s.qrange + (long)BL_QWORDS * sim, lo, hi);
+    const float rden = hi - lo + 1.e-4f;
+    const float cpuct = h2f(s.c_puct[b]);
+    uint32_t qp;                                    // transition_q (cuda.cu:101-105) of slot `lane`, both seats, f16 bits
+    {
+        const float den = (float)nn + 1.e-4f;
+        const float q0 = h2f((uint16_t)wp) / den, q1 = h2f((uint16_t)(wp >> 16)) / den;
+        qp = (uint32_t)f2h((q0 - lo) / rden) | ((uint32_t)f2h((q1 - lo) / rden) << 16);
+    }
+    auto pick = [&](int reg, int t) { return __builtin_amdgcn_readfirstlane(__builtin_amdgcn_readlane(reg, t & 63)); };
+
+    // policy() + the draw (cuda.cu:70-99, 35-68, 157-176) at nodes tA (lanes 0..31) and tB (lanes 32..63; -1: none).
+    // res[k] = {action (-1: none with positive probability; -2: node not evaluated), child slot (-1: not expanded), index
+    // in the compacted row}
+    auto evaluate2 = [&](const int tA, const int infoA, const int tB, const int infoB, int (&res)[2][3]) {
+        const bool evB = tB >= 0 && !((infoB >> 17) & 1);
+        const int nkA = infoA & 0xffff, nkB = evB ? (infoB & 0xffff) : 0;
+        const int nk = hiNode ? nkB : nkA;
+        const int seat = ((hiNode ? infoB : infoA) >> 16) & 1;
+        const int tmine = hiNode ? (evB ? tB : 0) : tA;
+        const int nkmax = nkA > nkB ? nkA : nkB;
+        const int R = (nkmax + 15) >> 4;
+        const float rnd = h2f((uint16_t)(hiNode ? pick(rd, evB ? tB : 0) : pick(rd, tA)));
+        const long row = (envbase + tmine) * A;
+
+        float top[RB], q[RB], term[RB], x[RB];
+        uint32_t cc[RB];
+        bool in[RB];
+#pragma unroll
+        for (int r = 0; r < RB; r++) {
+            const int e = 16 * r + el;
+            in[r] = (r < R) && (e < nk);
+            top[r] = 0.f; cc[r] = 0xffff0000u; q[r] = 0.f; term[r] = 0.f; x[r] = 0.f;
+            if (in[r]) { top[r] = s.cpi[row + e]; cc[r] = s.cca[row + e]; }
+        }
+        int Nloc = 0;
+#pragma unroll
+        for (int r = 0; r < RB; r++) {
+            if (r < R) {                                                  // wave-uniform: the bpermutes run with every lane enabled
+                const int c = (int)(int16_t)(cc[r] >> 16);
+                const bool ex = c >= 0;
+                const int src = ex ? c : 0;
+                const uint32_t q2 = (uint32_t)bperm_i(src & 63, (int)qp);
+                const int nv = bperm_i(src & 63, nn);
+                if (ex) q[r] = h2f((uint16_t)(seat ? (q2 >> 16) : q2));
+                if (isS && in[r]) Nloc += ex ? nv : 1;
+            }
+        }
+        Nloc = row_sum_i32(Nloc);                                         // rows 0 and 2 hold the two nodes' sums (rows 1, 3: zero)
+        const int NA = __builtin_amdgcn_readlane(Nloc, 15) + (A - nkA), NB = __builtin_amdgcn_readlane(Nloc, 47) + (A - nkB);
+        const int N = hiNode ? NB : NA;                                   // dropped actions are unexpanded: +1 each
+        const float lam = (cpuct * (float)N) / (float)(unsigned)(N + A);
+        float alpha = (nk < A) ? 1.e-4f : 0.f;                            // a dropped action's q + max(lambda pi, 1e-4)
+#pragma unroll
+        for (int r = 0; r < RB; r++) {
+            top[r] = lam * top[r];
+            if (in[r]) alpha = fmaxf(alpha, q[r] + fmaxf(top[r], 1.e-4f));
+        }
+        alpha = row_max_f32(alpha);                                       // both rows of a node hold the same elements
+        {
+            const float aA = readlane_f(alpha, 15), aB = readlane_f(alpha, 47);
+            alpha = hiNode ? aB : aA;
+        }
+
+        // newton_search, cuda.cu:35-68, both nodes in step; a node that has converged keeps its alpha (its terms and totals are
+        // then recomputed unchanged) until the other one has, too
+        bool doneA = nkA == 0, doneB = nkB == 0;
+        float errA = INFINITY, errB = INFINITY;
+        const int lastA = nkA - 1, lastB = nkB - 1;
+        const int rlA = lastA >> 4, rlB = lastB >> 4;
+        for (int it = 0; it < 101 && !(doneA && doneB); it++) {
+#pragma unroll
+            for (int r = 0; r < RB; r++) {
+                if (r < R) {
+                    const float bot = alpha - q[r];
+                    const float num = isS ? top[r] : -top[r];
+                    const float den = isS ? bot : bot * bot;
+                    term[r] = in[r] ? num / den : 0.f;                    // prob(a), cuda.cu:23-25, resp. its derivative term
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < RB; r++) {
+                if (r < R) {
+                    x[r] = term[r];
+                    if (r == 0) { if (el == 0) x[0] = 0.f + x[0]; }          // the sums start from 0.f (cuda.cu:44): (+0) + (-0) = +0
+                    else fold_ror<FAST>(x[r], x[r - 1 < 0 ? 0 : r - 1], term[r]);
+                    fold7<FAST>(x[r], term[r]);
+                    if (nkmax - 16 * r > 8) fold8<FAST>(x[r], term[r]);
+                }
+            }
+            float SA = 0.f, gA = 0.f, SB = 0.f, gB = 0.f;
+#pragma unroll
+            for (int r = 0; r < RB; r++) {
+                if (r == rlA) { SA = readlane_f(x[r], lastA & 15); gA = readlane_f(x[r], 16 + (lastA & 15)); }
+                if (r == rlB) { SB = readlane_f(x[r], 32 + (lastB & 15)); gB = readlane_f(x[r], 48 + (lastB & 15)); }
+            }
+            if (it == 100) break;      // alpha moved after the 100th fold (cuda.cu:48-65): this pass only refreshed the terms
+            const float neA = SA - 1.f, neB = SB - 1.f;
+            if (!doneA && ((neA < 1e-3f) || (errA == neA))) doneA = true;
+            if (!doneB && ((neB < 1e-3f) || (errB == neB))) doneB = true;
+            const float ne = hiNode ? neB : neA, gs = hiNode ? gB : gA;
+            const bool frozen = hiNode ? doneB : doneA;
+            const float step = ne / gs;
+            if (!frozen) alpha -= step;
+            if (!doneA) errA = neA;
+            if (!doneB) errB = neB;
+        }
+
+        // the draw, cuda.cu:157-176: first kept action (ascending) with prob > 0 and running total >= rand, else the last
+        // with prob > 0.  Rows 0 / 2 hold prob in term[r] and the running totals in x[r].
+        int selr[2] = {-1, -1}, sell[2] = {0, 0}, lastr[2] = {-1, -1}, lastl[2] = {0, 0};
+#pragma unroll
+        for (int r = 0; r < RB; r++) {
+            if (r < R) {
+                const bool pos = in[r] && isS && term[r] > 0.f;
+                const unsigned long long hit = __ballot(pos && x[r] >= rnd), anyp = __ballot(pos);
+#pragma unroll
+                for (int k = 0; k < 2; k++) {
+                    const uint32_t h = (uint32_t)(hit >> (32 * k)) & 0xffffu, p = (uint32_t)(anyp >> (32 * k)) & 0xffffu;
+                    if (selr[k] < 0 && h) { selr[k] = r; sell[k] = 32 * k + __builtin_ctz(h); }
+                    if (p) { lastr[k] = r; lastl[k] = 32 * k + 31 - __builtin_clz(p); }
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            if (selr[k] < 0) { selr[k] = lastr[k]; sell[k] = lastl[k]; }
+            res[k][0] = -1; res[k][1] = -1; res[k][2] = 0;
+            if (selr[k] >= 0) {
+                uint32_t ccs = 0;
+#pragma unroll
+                for (int r = 0; r < RB; r++) if (r == selr[k]) ccs = (uint32_t)__builtin_amdgcn_readlane((int)cc[r], sell[k]);
+                res[k][0] = (int)(ccs & 0xffffu);
+                res[k][2] = 16 * selr[k] + (sell[k] & 15);
+                res[k][1] = __builtin_amdgcn_readfirstlane((int)(int16_t)(ccs >> 16));
+            }
+        }
+        if (!evB) res[1][0] = -2;
+    };
+
+    // ---- descend_kernel's loop, cuda.cu:138-182, two guessed levels at a time
+    int t = 0, parent = 0, action = -1, nlev = 0, sel_e = 0;
+    int tinfo = pick(info, 0);
+    bool live = true;
+    for (int batch = 0; batch < T; batch++) {
+        if (!live || t == -1 || ((tinfo >> 17) & 1) || nlev >= T) break;
+        const int u0 = t, u0info = tinfo;
+        int u1 = pick(fav, u0), u1info = 0;
+        if (u1 != -1) u1info = pick(info, u1);
+        int res[2][3];
+        evaluate2(u0, u0info, u1, u1info, res);
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            const int node = k ? u1 : u0;
+            if (path && lane == 0) path[1 + nlev] = (int16_t)node;
+            nlev++;
+            parent = node; sel_e = res[k][2];
+            if (res[k][0] < 0) { action = -1; live = false; break; }     // no action with positive probability: the reference would index [-1]
+            action = res[k][0];
+            {
+                // node's most visited child once this descent is backed up: the drawn child gains a visit (n += 2)
+                const int cnew = res[k][1] == -1 ? sim : res[k][1];
+                const int f_old = pick(fav, node);
+                if (f_old == -1 || pick(nn, cnew) + 2 >= pick(nn, f_old)) { if (lane == node) fav = cnew; }
+            }
+            t = res[k][1];
+            if (t == -1) break;
+            tinfo = pick(info, t);
+            if ((tinfo >> 17) & 1) break;
+            if (!(k == 0 && u1 == t && res[1][0] != -2)) break;          // the guess ends here: next batch starts at t
+        }
+    }
+    if (action < 0) action = 0;
+    if (lane < T) s.fav[envbase + lane] = (int16_t)fav;
+
+    // ---- leaves = children[envs, parents, actions]; leaves[leaves == -1] = sim   (mcts/__init__.py:117-122); Hex.step + observe
+    const int nxt = t;
+    const int leaf = (nxt == -1) ? sim : nxt;
+    if (lane == 0) {
+        s.children[(envbase + parent) * A + action] = (int16_t)leaf;
+        s.parents[envbase + leaf] = (int16_t)parent;
+        s.relation[envbase + leaf] = (int16_t)action;
+        if (nxt == -1 && nlev > 0) ((uint16_t*)(s.cca + (envbase + parent) * A + sel_e))[1] = (uint16_t)leaf;   // the compacted row's child field
+    }
+    const int seat = s.seats[envbase + parent];
+    const uint8_t* src = s.boards + (envbase + parent) * A;
+    for (int a = lane; a < A; a += 64) cells[a] = src[a];
+    __syncthreads();
+    const int win = hex_step_group<64>(cells, S, seat, action, true, lane);
+    const bool term = win != 0;                                          // Hex.step tail, hex/__init__.py:183-190
+    const int new_seat = term ? 0 : 1 - seat;
+    uint8_t* dst = s.boards + (envbase + leaf) * A;
+    const float invS = 1.0f / (float)S;
+    const bool flip = new_seat == 1;
+    for (int a = lane; a < A; a += 64) dst[a] = term ? (uint8_t)0 : cells[a];
+    for (int a = lane; a < A; a += 64) {
+        const int i = (int)(((float)a + 0.5f) * invS), j = a - i * S;
+        const int color = term ? 2 : color_of(cells[flip ? j * S + i : a]);
+        const int ch = color < 2 ? (flip ? 1 - color : color) : 2;
+        if (s.obs_f16) ((uint32_t*)obs_out)[(long)b * A + a] = ch == 0 ? 0x00003c00u : (ch == 1 ? 0x3c000000u : 0u);   // f16 1.0 = 0x3c00
+        else ((float2*)obs_out)[(long)b * A + a] = make_float2(ch == 0 ? 1.f : 0.f, ch == 1 ? 1.f : 0.f);
+        valid_out[(long)b * A + a] = color == 2;
+    }
+    if (lane == 0) {
+        s.seats[envbase + leaf] = new_seat;
+        s.terminal[envbase + leaf] = term;
+        s.rewards[(envbase + leaf) * 2 + 0] = f2h((float)win);
+        s.rewards[(envbase + leaf) * 2 + 1] = f2h((float)(-win));
+        leaves_out[b] = (int16_t)leaf;
+        leaf_seats_out[b] = new_seat;
+        if (path) {
+            path[1 + nlev] = (int16_t)leaf;
+            path[0] = (int16_t)(nlev + 1);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 // Self-test of the FAST fold on the device at hand: random positive/negative terms through fold_carry / fold_rows /
 // fold_mid exactly as the kernel chains them, against a serial sum by lane 0 through LDS.  out[0] += mismatching totals.
 // ------------------------------------------------------------------------------------------------------------------
@@ -469,6 +735,17 @@ int bl_expand2_launch(const Search& ss, int sim, const void* rands, int16_t* lea
                       unsigned long long* counters, int fast, int waves, int deep_thresh, hipStream_t stream) {
     const int A = ss.S * ss.S, T = ss.T;
     if (!ss.cpi || !ss.cca || !ss.nk || A > 384 || T > 256) return BL_ETOOBIG;
+    if (waves == 21 && ss.fav && A <= 96 && T <= 64 && !counters) {
+        // two nodes per wave (sim_expand3_kernel)
+        const dim3 grid3(ss.B), block3(64);
+        const size_t lds3 = (size_t)al16(A);
+#define BLX3(RB_) { if (fast) hipLaunchKernelGGL((sim_expand3_kernel<RB_, true>), grid3, block3, lds3, stream, ss, sim, (const uint16_t*)rands, leaves, obs, valid, leaf_seats); \
+                    else hipLaunchKernelGGL((sim_expand3_kernel<RB_, false>), grid3, block3, lds3, stream, ss, sim, (const uint16_t*)rands, leaves, obs, valid, leaf_seats); }
+        const int rb = (A + 15) / 16;
+        if (rb <= 1) BLX3(1) else if (rb <= 2) BLX3(2) else if (rb <= 4) BLX3(4) else BLX3(6)
+#undef BLX3
+        return hipGetLastError() == hipSuccess ? BL_OK : BL_ELAUNCH;
+    }
     if ((waves != 4 && waves != 2) || !ss.fav) waves = 1;
     const int need = (A + 31) / 32;
     const int rmax = need <= 1 ? 1 : need <= 2 ? 2 : need <= 3 ? 3 : need <= 6 ? 6 : 12;

@@ -606,6 +606,21 @@ def test_narrow_group_paths_in_subprocess(group):
     assert ' passed' in r.stdout
 
 
+def test_two_nodes_per_wave_expand_in_subprocess():
+    """bl_expand.hip's sim_expand3_kernel (one wave per env evaluating the current node and its guessed continuation in its two
+    halves; BL_EXPAND_WAVES=21, read once per process) is a measured alternative, not the default: the same full-size oracle
+    comparisons must hold for it bit for bit."""
+    import subprocess, sys
+    env = dict(os.environ, BL_EXPAND_WAVES='21')
+    here = os.path.dirname(os.path.abspath(__file__))
+    r = subprocess.run([sys.executable, '-m', 'pytest', os.path.join(here, 'test_gpu_parity.py'), '-q', '-x', '-m', 'gpu',
+                        '-k', '(test_whole_search_replay and fused) or (test_full_size_search_vs_oracle and 9-4096-64) or '
+                              '(test_bench_launch_sequence_vs_oracle and 9-4096-64-512-4-graph) or test_search_with_per_env_c_puct'],,
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert ' passed' in r.stdout
+
+
 # ------------------------------------------------------------------------------------------------ widened rows (SURVEY 8f)
 @pytest.mark.parametrize('inference,graph', [(None, False), ('fused', True)])
 def test_actor_learner_loop_runs_and_learns_something(inference, graph):
