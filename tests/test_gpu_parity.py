@@ -615,7 +615,7 @@ def test_two_nodes_per_wave_expand_in_subprocess():
     here = os.path.dirname(os.path.abspath(__file__))
     r = subprocess.run([sys.executable, '-m', 'pytest', os.path.join(here, 'test_gpu_parity.py'), '-q', '-x', '-m', 'gpu',
                         '-k', '(test_whole_search_replay and fused) or (test_full_size_search_vs_oracle and 9-4096-64) or '
-                              '(test_bench_launch_sequence_vs_oracle and 9-4096-64-512-4-graph) or test_search_with_per_env_c_puct'],,
+                              '(test_bench_launch_sequence_vs_oracle and 9-4096-64-512-4-graph) or test_search_with_per_env_c_puct'],
                        env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert ' passed' in r.stdout
