@@ -45,6 +45,61 @@ template <int G> __device__ __forceinline__ uint32_t gmaxu(uint32_t x) {
     return x;
 }
 
+// a / b, correctly rounded: instruction for instruction the sequence the compiler emits for `a / b` (LowerFDIV32 with fp32
+// denormals on).  The compiler's own expansion hands the numerator's scale flag from v_div_scale to v_div_fmas in VCC, so two
+// quotients can only follow each other; here the flag waits in an ordinary SGPR pair and VCC is loaded right before the
+// v_div_fmas, so the FMA chains of independent quotients (the blocks of a Newton iteration, the two seats of a slot) interleave.
+// (s_nop 3: the ISA's wait states between a write of VCC and v_div_fmas, which the assembler does not insert inside asm.)
+__device__ __forceinline__ float ieee_div(float a, float b) {
+    float ds, ns, q;
+    unsigned long long fd, fn;
+    asm("v_div_scale_f32 %0, %1, %3, %3, %2" : "=v"(ds), "=s"(fd) : "v"(a), "v"(b));     // denominator scaled
+    asm("v_div_scale_f32 %0, %1, %2, %3, %2" : "=v"(ns), "=s"(fn) : "v"(a), "v"(b));     // numerator scaled; its flag steers v_div_fmas
+    const float r = __builtin_amdgcn_rcpf(ds);
+    const float nd = -ds;
+    const float f0 = __builtin_fmaf(nd, r, 1.0f);
+    const float f1 = __builtin_fmaf(f0, r, r);
+    const float m = ns * f1;
+    const float f2 = __builtin_fmaf(nd, m, ns);
+    const float f3 = __builtin_fmaf(f2, f1, m);
+    const float f4 = __builtin_fmaf(nd, f3, ns);
+    asm("s_mov_b64 vcc, %1\n\ts_nop 3\n\tv_div_fmas_f32 %0, %2, %3, %4" : "=v"(q) : "s"(fn), "v"(f4), "v"(f1), "v"(f3) : "vcc");
+    return __builtin_amdgcn_div_fixupf(q, b, a);
+}
+
+// N independent quotients with their dependent chains written side by side, step by step: left to itself the scheduler emits
+// one quotient after the other (its latency model sees nothing to gain), and a wave that has the SIMD to itself then waits
+// out every chain in turn.
+template <int N>
+__device__ __forceinline__ void ieee_div_n(const float (&a)[N], const float (&b)[N], float (&q)[N]) {
+    float ds[N], ns[N], r[N], f0[N], f1[N], m[N], f2[N], f3[N], f4[N];
+    unsigned long long fd[N], fn[N];
+#pragma unroll
+    for (int n = 0; n < N; n++) asm("v_div_scale_f32 %0, %1, %3, %3, %2" : "=v"(ds[n]), "=s"(fd[n]) : "v"(a[n]), "v"(b[n]));
+#pragma unroll
+    for (int n = 0; n < N; n++) asm("v_div_scale_f32 %0, %1, %2, %3, %2" : "=v"(ns[n]), "=s"(fn[n]) : "v"(a[n]), "v"(b[n]));
+#pragma unroll
+    for (int n = 0; n < N; n++) r[n] = __builtin_amdgcn_rcpf(ds[n]);
+#pragma unroll
+    for (int n = 0; n < N; n++) f0[n] = __builtin_fmaf(-ds[n], r[n], 1.0f);
+#pragma unroll
+    for (int n = 0; n < N; n++) f1[n] = __builtin_fmaf(f0[n], r[n], r[n]);
+#pragma unroll
+    for (int n = 0; n < N; n++) m[n] = ns[n] * f1[n];
+#pragma unroll
+    for (int n = 0; n < N; n++) f2[n] = __builtin_fmaf(-ds[n], m[n], ns[n]);
+#pragma unroll
+    for (int n = 0; n < N; n++) f3[n] = __builtin_fmaf(f2[n], f1[n], m[n]);
+#pragma unroll
+    for (int n = 0; n < N; n++) f4[n] = __builtin_fmaf(-ds[n], f3[n], ns[n]);
+#pragma unroll
+    for (int n = 0; n < N; n++) {
+        float t;
+        asm("s_mov_b64 vcc, %1\n\ts_nop 3\n\tv_div_fmas_f32 %0, %2, %3, %4" : "=v"(t) : "s"(fn[n]), "v"(f4[n]), "v"(f1[n]), "v"(f3[n]) : "vcc");
+        q[n] = __builtin_amdgcn_div_fixupf(t, b[n], a[n]);
+    }
+}
+
 // Reduce the 64 qrange slots: every lane of the wave returns {lo, hi}.  transition_q, cuda.cu:101-105.
 __device__ __forceinline__ void load_qrange(const uint32_t* qr, float& lo, float& hi) {
     const int lane = threadIdx.x & 63;

@@ -25,6 +25,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <math.h>
+#include <type_traits>
 #include "../../include/boardlaw_amd.h"
 #include "bl_device.h"
 
@@ -218,11 +219,57 @@ __global__ void __launch_bounds__(BL_WAVE * NW, (RMAX <= 3 ? 8 : 4)) sim_expand2
         alpha = wave_max_f32(alpha);
         if (COUNT) tsetup += clock64() - tp0;
 
-        // newton_search, cuda.cu:35-68
+        // newton_search, cuda.cu:35-68.  The iteration body is instantiated per block count (`RR` = R, fixed for the call): with
+        // the blocks behind run-time branches each block's IEEE division was a basic block of its own, one dependent chain
+        // after the other; as straight-line code the chains of all blocks interleave, and block 0's fold starts while the
+        // later blocks' quotients are still in flight.
         float err = INFINITY;
         int iters = 0;
         const int last_e = nk - 1, rl = last_e >> 5;
         const int laneS = (last_e & 31) + ((rl & 1) ? 32 : 0), laneG = (last_e & 31) + ((rl & 1) ? 0 : 32);
+        auto newton = [&](auto rr_c) __attribute__((always_inline)) {
+            constexpr int RR = decltype(rr_c)::value;
+            for (int it = 0; it < 101 && nk > 0; it++) {
+                long long ti0 = 0, ti1 = 0, ti2 = 0;
+                if (COUNT) ti0 = clock64();
+                // prob(a), cuda.cu:23-25, resp. its derivative term.  No `in[r] ?` on the quotient: lanes beyond the row's end hold
+                // top = 0, q = 0, so they get +-0 / alpha^k -- and nothing ever reads them (prefix sums only flow upwards, the totals
+                // are read at the last kept action, the draw tests in[r]); a select would put every quotient behind its own EXEC
+                // branch, one dependent chain after the other.
+                float num[RR], den[RR], quo[RR];
+#pragma unroll
+                for (int r = 0; r < RR; r++) {
+                    const bool isS = lowhalf != ((r & 1) != 0);
+                    const float bot = alpha - q[r];
+                    num[r] = isS ? top[r] : -top[r];
+                    den[r] = isS ? bot : bot * bot;
+                }
+                ieee_div_n<RR>(num, den, quo);
+#pragma unroll
+                for (int r = 0; r < RR; r++) term[r] = quo[r];
+                if (COUNT) { ti1 = clock64(); tterms += ti1 - ti0; }
+#pragma unroll
+                for (int r = 0; r < RR; r++) {
+                    x[r] = term[r];
+                    if (r == 0) { if (el == 0) x[0] = 0.f + x[0]; }          // the sums start from 0.f (cuda.cu:44): (+0) + (-0) = +0
+                    else fold_carry<FAST>(x[r], x[r - 1 < 0 ? 0 : r - 1], term[r]);
+                    fold_block<FAST>(x[r], term[r], r + 1 < RR ? 32 : nk - 32 * r);
+                }
+                const float Ssum = readlane_f(x[RR - 1], laneS), gsum_ = readlane_f(x[RR - 1], laneG);      // rl == RR - 1
+                if (COUNT) { ti2 = clock64(); tfold += ti2 - ti1; }
+                if (it == 100) break;      // alpha moved after the 100th fold (cuda.cu:48-65): this pass only refreshed the terms
+                iters++;
+                const float ne = Ssum - 1.f;
+                if ((ne < 1e-3f) || (err == ne)) break;
+                alpha -= ne / gsum_; err = ne;
+                if (COUNT) tupd += clock64() - ti2;
+            }
+        };
+        if constexpr (RMAX <= 3) {
+            if (R <= 1) newton(std::integral_constant<int, 1>{});
+            else if (R == 2) newton(std::integral_constant<int, RMAX >= 2 ? 2 : 1>{});
+            else newton(std::integral_constant<int, RMAX >= 3 ? 3 : 1>{});
+        } else {
         for (int it = 0; it < 101 && nk > 0; it++) {
             long long ti0 = 0, ti1 = 0, ti2 = 0;
             if (COUNT) ti0 = clock64();
@@ -256,6 +303,7 @@ __global__ void __launch_bounds__(BL_WAVE * NW, (RMAX <= 3 ? 8 : 4)) sim_expand2
             if ((ne < 1e-3f) || (err == ne)) break;
             alpha -= ne / gsum_; err = ne;
             if (COUNT) tupd += clock64() - ti2;
+        }
         }
 
         // the draw, cuda.cu:157-176: first kept action (ascending) with prob > 0 and running total >= rand, else the last
