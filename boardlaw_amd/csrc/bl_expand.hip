@@ -265,10 +265,13 @@ __global__ void __launch_bounds__(BL_WAVE * NW, (RMAX <= 3 ? 8 : 4)) sim_expand2
                 if (COUNT) tupd += clock64() - ti2;
             }
         };
-        if constexpr (RMAX <= 3) {
+        if constexpr (RMAX <= 6) {
             if (R <= 1) newton(std::integral_constant<int, 1>{});
             else if (R == 2) newton(std::integral_constant<int, RMAX >= 2 ? 2 : 1>{});
-            else newton(std::integral_constant<int, RMAX >= 3 ? 3 : 1>{});
+            else if (R == 3) newton(std::integral_constant<int, RMAX >= 3 ? 3 : 1>{});
+            else if (R == 4) newton(std::integral_constant<int, RMAX >= 4 ? 4 : 1>{});
+            else if (R == 5) newton(std::integral_constant<int, RMAX >= 5 ? 5 : 1>{});
+            else newton(std::integral_constant<int, RMAX >= 6 ? 6 : 1>{});
         } else {
         for (int it = 0; it < 101 && nk > 0; it++) {
             long long ti0 = 0, ti1 = 0, ti2 = 0;

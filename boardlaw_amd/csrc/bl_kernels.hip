@@ -759,7 +759,10 @@ __global__ void __launch_bounds__(BL_WAVE) sim_backup_kernel(Search s, int sim, 
     if (act) {
         for (int e = gl; e < T; e += G) {
             const float den = (float)s.n[envbase + e] + 1.e-4f;
-            const uint32_t e0 = enc(h2f(s.w[(envbase + e) * 2]) / den), e1 = enc(h2f(s.w[(envbase + e) * 2 + 1]) / den);
+            const float qa_[2] = {h2f(s.w[(envbase + e) * 2]), h2f(s.w[(envbase + e) * 2 + 1])}, qb_[2] = {den, den};
+            float qq_[2];
+            ieee_div_n<2>(qa_, qb_, qq_);                      // both seats' quotients side by side (bl_device.h)
+            const uint32_t e0 = enc(qq_[0]), e1 = enc(qq_[1]);
             nmin = max(nmin, max(~e0, ~e1)); vmax = max(vmax, max(e0, e1));
         }
     }
@@ -856,7 +859,10 @@ __global__ void __launch_bounds__(BL_WAVE) sim_finish_kernel(Search s, int sim, 
     uint32_t nmin = 0, vmax = 0;
     for (int e = lane; e < T; e += BL_WAVE) {
         const float den = (float)s.n[envbase + e] + 1.e-4f;
-        const uint32_t e0 = enc(h2f(s.w[(envbase + e) * 2]) / den), e1 = enc(h2f(s.w[(envbase + e) * 2 + 1]) / den);
+        const float qa_[2] = {h2f(s.w[(envbase + e) * 2]), h2f(s.w[(envbase + e) * 2 + 1])}, qb_[2] = {den, den};
+        float qq_[2];
+        ieee_div_n<2>(qa_, qb_, qq_);                          // both seats' quotients side by side (bl_device.h)
+        const uint32_t e0 = enc(qq_[0]), e1 = enc(qq_[1]);
         nmin = max(nmin, max(~e0, ~e1)); vmax = max(vmax, max(e0, e1));
     }
     nmin = wave_max_u32(nmin); vmax = wave_max_u32(vmax);
