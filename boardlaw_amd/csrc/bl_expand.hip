@@ -575,43 +575,50 @@ __global__ void __launch_bounds__(BL_WAVE) sim_expand3_kernel(Search s, int sim,
         float errA = INFINITY, errB = INFINITY;
         const int lastA = nkA - 1, lastB = nkB - 1;
         const int rlA = lastA >> 4, rlB = lastB >> 4;
-        for (int it = 0; it < 101 && !(doneA && doneB); it++) {
+        auto newton = [&](auto rr_c) __attribute__((always_inline)) {      // body per block count, quotients side by side: see sim_expand2_kernel
+            constexpr int RR = decltype(rr_c)::value;
+            for (int it = 0; it < 101 && !(doneA && doneB); it++) {
+                float num[RR], den[RR], quo[RR];
 #pragma unroll
-            for (int r = 0; r < RB; r++) {
-                if (r < R) {
+                for (int r = 0; r < RR; r++) {
                     const float bot = alpha - q[r];
-                    const float num = isS ? top[r] : -top[r];
-                    const float den = isS ? bot : bot * bot;
-                    term[r] = in[r] ? num / den : 0.f;                    // prob(a), cuda.cu:23-25, resp. its derivative term
+                    num[r] = isS ? top[r] : -top[r];
+                    den[r] = isS ? bot : bot * bot;
                 }
-            }
+                ieee_div_n<RR>(num, den, quo);                            // prob(a), cuda.cu:23-25, resp. its derivative term
 #pragma unroll
-            for (int r = 0; r < RB; r++) {
-                if (r < R) {
+                for (int r = 0; r < RR; r++) {
+                    term[r] = quo[r];
                     x[r] = term[r];
                     if (r == 0) { if (el == 0) x[0] = 0.f + x[0]; }          // the sums start from 0.f (cuda.cu:44): (+0) + (-0) = +0
                     else fold_ror<FAST>(x[r], x[r - 1 < 0 ? 0 : r - 1], term[r]);
                     fold7<FAST>(x[r], term[r]);
-                    if (nkmax - 16 * r > 8) fold8<FAST>(x[r], term[r]);
+                    if (r + 1 < RR || nkmax - 16 * r > 8) fold8<FAST>(x[r], term[r]);
                 }
-            }
-            float SA = 0.f, gA = 0.f, SB = 0.f, gB = 0.f;
+                float SA = 0.f, gA = 0.f, SB = 0.f, gB = 0.f;
 #pragma unroll
-            for (int r = 0; r < RB; r++) {
-                if (r == rlA) { SA = readlane_f(x[r], lastA & 15); gA = readlane_f(x[r], 16 + (lastA & 15)); }
-                if (r == rlB) { SB = readlane_f(x[r], 32 + (lastB & 15)); gB = readlane_f(x[r], 48 + (lastB & 15)); }
+                for (int r = 0; r < RR; r++) {
+                    if (r == rlA) { SA = readlane_f(x[r], lastA & 15); gA = readlane_f(x[r], 16 + (lastA & 15)); }
+                    if (r == rlB) { SB = readlane_f(x[r], 32 + (lastB & 15)); gB = readlane_f(x[r], 48 + (lastB & 15)); }
+                }
+                if (it == 100) break;      // alpha moved after the 100th fold (cuda.cu:48-65): this pass only refreshed the terms
+                const float neA = SA - 1.f, neB = SB - 1.f;
+                if (!doneA && ((neA < 1e-3f) || (errA == neA))) doneA = true;
+                if (!doneB && ((neB < 1e-3f) || (errB == neB))) doneB = true;
+                const float ne = hiNode ? neB : neA, gs = hiNode ? gB : gA;
+                const bool frozen = hiNode ? doneB : doneA;
+                const float step = ne / gs;
+                if (!frozen) alpha -= step;
+                if (!doneA) errA = neA;
+                if (!doneB) errB = neB;
             }
-            if (it == 100) break;      // alpha moved after the 100th fold (cuda.cu:48-65): this pass only refreshed the terms
-            const float neA = SA - 1.f, neB = SB - 1.f;
-            if (!doneA && ((neA < 1e-3f) || (errA == neA))) doneA = true;
-            if (!doneB && ((neB < 1e-3f) || (errB == neB))) doneB = true;
-            const float ne = hiNode ? neB : neA, gs = hiNode ? gB : gA;
-            const bool frozen = hiNode ? doneB : doneA;
-            const float step = ne / gs;
-            if (!frozen) alpha -= step;
-            if (!doneA) errA = neA;
-            if (!doneB) errB = neB;
-        }
+        };
+        if (R <= 1) newton(std::integral_constant<int, 1>{});
+        else if (R == 2) newton(std::integral_constant<int, RB >= 2 ? 2 : 1>{});
+        else if (R == 3) newton(std::integral_constant<int, RB >= 3 ? 3 : 1>{});
+        else if (R == 4) newton(std::integral_constant<int, RB >= 4 ? 4 : 1>{});
+        else if (R == 5) newton(std::integral_constant<int, RB >= 5 ? 5 : 1>{});
+        else newton(std::integral_constant<int, RB >= 6 ? 6 : 1>{});
 
         // the draw, cuda.cu:157-176: first kept action (ascending) with prob > 0 and running total >= rand, else the last
         // with prob > 0.  Rows 0 / 2 hold prob in term[r] and the running totals in x[r].
