@@ -1,5 +1,5 @@
 """600 self-play moves of bench.py's configuration on one captured graph: rate over a long run (positions drift from the bench's
-pre-mixed boards to the stationary mix of a self-play run: 41.3 M sims/s), allocator growth, legality.  GPU box: python tools/soak.py"""
+pre-mixed boards to the stationary mix of a self-play run: 44.6 M sims/s), allocator growth, legality.  GPU box: python tools/soak.py"""
 import sys, time, torch
 sys.path.insert(0, '.')
 from boardlaw_amd import networks
