@@ -729,14 +729,36 @@ __global__ void __launch_bounds__(256) layer_kernel(LayerArgs a) {
             }
         }
     } else {
-        // rows that are only 4-byte aligned (the observation: 2 planes per cell): 32-bit words
-        if (active) gemm_prefetch<1, RD>(rg, a.Wp, a.Kpad, tile, 1);
+        // rows that are only 4-byte aligned (the observation: 2 planes per cell): 32-bit words.  Wave w stages rows 8w .. 8w+7,
+        // lane l their words l, l + 64, ...; a row's loads all in flight at once (Kpad <= 1024: at most 8 per lane and row)
         const int wpr = a.Kpad >> 1, wvalid = a.Kvalid >> 1;
-        for (int c = tid; c < 32 * wpr; c += 256) {
-            const int r = c / wpr, w = c - r * wpr;
-            uint32_t v = (row0 + r < a.M && w < wvalid) ? ((const uint32_t*)a.X)[((long)(row0 + r) * a.ldx >> 1) + w] : 0u;
-            if (a.relu_in) v = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(half2v, v), z2));
-            ((uint32_t*)R)[r * (ld >> 1) + w] = v;
+        constexpr int WMAX = 8;
+        uint32_t v[8][WMAX];
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const int r = wave * 8 + i;
+            const bool rok = row0 + r < a.M;
+            const uint32_t* src = (const uint32_t*)a.X + ((long)(row0 + r) * a.ldx >> 1);
+#pragma unroll
+            for (int k = 0; k < WMAX; k++) {
+                const int w = lane + 64 * k;
+                v[i][k] = 0u;
+                if (64 * k < wvalid) { if (rok && w < wvalid) v[i][k] = src[w]; }
+            }
+        }
+        if (active) gemm_prefetch<1, RD>(rg, a.Wp, a.Kpad, tile, 1);      // behind the rows' loads: vmcnt retires in order
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const int r = wave * 8 + i;
+#pragma unroll
+            for (int k = 0; k < WMAX; k++) {
+                const int w = lane + 64 * k;
+                if (w < wpr) {
+                    uint32_t x = v[i][k];
+                    if (a.relu_in) x = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(half2v, x), z2));
+                    ((uint32_t*)R)[r * (ld >> 1) + w] = x;
+                }
+            }
         }
     }
     __syncthreads();
@@ -862,6 +884,8 @@ extern "C" int bl_mlp_layers_f16(const void* obs, int M, int K0, const void* w0,
             case 768: BL_LAYER_LAUNCH(8, 12) break;
             case 512: BL_LAYER_LAUNCH(6, 8) break;
             case 256: BL_LAYER_LAUNCH(4, 4) break;
+            case 384: BL_LAYER_LAUNCH(6, 6) break;      // 13x13's intake
+            case 192: BL_LAYER_LAUNCH(3, 3) break;      // 9x9's intake
             default: BL_LAYER_LAUNCH(3, 0) break;
         }
 #undef BL_LAYER_LAUNCH

@@ -73,7 +73,7 @@ class Inference:
     # (64 B/clk).  Up to FUSED_ALWAYS_BYTES of weights (512x4: 2.4 MB, 28 us) that beats a launch per Linear at any batch size;
     # beyond it (1024x8: 17.9 MB, 170 us) only once the batch gives FUSED_MIN_TILES workgroups.  Below that every Linear is
     # its own launch, split over all CUs (bl_mlp_layers_f16; us per forward at 13x13, one kernel / launch per Linear / library
-    # GEMMs: 1024x8 on 1024 rows 170 / 101 / 133, on 2048 rows 166 / 131 / 159, on 4096 rows 165 / 215 / 202; 768x6 on
+    # GEMMs: 1024x8 on 1024 rows 170 / 95 / 133, on 2048 rows 166 / 131 / 159, on 4096 rows 165 / 215 / 202; 768x6 on
     # 2048 rows 92 / 87 / 106, on 4096 rows 92 / 127 / 138).
     FUSED_ALWAYS_BYTES = 6 << 20
     FUSED_MIN_TILES = 96
