@@ -228,8 +228,8 @@ def main():
         return
     value_torch_rng = None
     if world == 1 and not args.eager and not args.no_reference_rng:
-        # the same moves with the reference's RNG protocol: one rand_like (B,T) f16 per simulation (cuda.cu:191) instead of
-        # MoveRng's one block per move -- same amount of randomness, 62 more small launches per move
+        # the same moves with the reference's RNG protocol issued call by call: one rand_like (B,T) f16 per simulation
+        # (cuda.cu:191) instead of MoveRng's one launch per move -- the same numbers from the same seed, 62 more launches per move
         from boardlaw_amd.mcts import TorchRng
         ref_agent = MCTSAgent(agent.network, n_nodes=NODES, graph=True, rng=TorchRng())
         w2 = worlds
@@ -327,7 +327,7 @@ def main():
                                    if args.torch_gemms
                                    else 'a launch per Linear, bl_mlp_layers_f16 (autocast rounding points), + bl_sim_finish' if not agent.network.prefers_fused(args.envs)
                                    else 'fused MFMA kernel bl_sim_infer_finish (autocast rounding points; <= 1 f16 ulp vs autocast)') + '; root evaluation fp32',
-                       'rng': 'MoveRng: torch generator, the T-1 descend uniforms of a move drawn as ONE (T-1,B,T) f16 block instead of T-1 rand_like calls',
+                       'rng': 'MoveRng: stream-identical to the reference protocol (torch generator; Dirichlet and Categorical are torch\'s own calls; the T-1 rand_like (B,T) f16 draws of a move come from ONE launch, bl_rand_block, that evaluates the Philox counters those calls would use and advances the generator by what they would consume -- tests/test_rng_stream.py)',
                        'value_reference_rng_protocol': value_torch_rng,
                        'search_kernels_only': search_only,
                        'two_actors_per_gpu': two_actors,

@@ -53,6 +53,7 @@ SYMBOLS = {
     'bl_sim_compact': (_i, [ctypes.POINTER(Search), _vp, _vp]),
     'bl_draw_actions': (_i, [_vp, _vp, _vp, _i, _i, _vp]),
     'bl_copy_many': (_i, [_vp, _i, _vp]),
+    'bl_rand_block': (_i, [_vp, _i, ctypes.c_long, ctypes.c_long, _i, ctypes.c_ulonglong, ctypes.c_ulonglong, ctypes.c_uint, _i, _vp]),
     'bl_selftest': (_i, [_vp]),
     'bl_fold_variant': (_i, []),
 }
@@ -83,6 +84,27 @@ def lib():
             if rc < 0:
                 raise NativeError(f'libboardlaw_amd: device self-test failed ({L.bl_strerror(rc).decode()})')
     return _lib
+
+
+GENLIBPATH = os.path.join(HERE, 'libbl_torchgen.so')
+_genlib = None
+
+
+def philox_state(generator, increment):
+    """What a torch random kernel gets from `gen->philox_cuda_state(increment)` (csrc/bl_torchgen.cpp): (seed, offset,
+    offset_intragraph, captured) -- seed/offset are device pointers when `captured` (inside HIP-graph capture).  Advances the
+    generator by `increment` like the torch kernel it stands in for."""
+    global _genlib
+    if _genlib is None:
+        if not os.path.exists(GENLIBPATH):
+            raise NativeError(f'{GENLIBPATH} is missing: run `python -m boardlaw_amd.build`')
+        L = ctypes.CDLL(GENLIBPATH)
+        L.bl_torch_philox_state.restype, L.bl_torch_philox_state.argtypes = _i, [_vp, ctypes.c_uint64, ctypes.POINTER(ctypes.c_int64)]
+        _genlib = L
+    out = (ctypes.c_int64 * 4)()
+    if _genlib.bl_torch_philox_state(generator._cdata, increment, out) != 0:
+        raise NativeError('bl_torch_philox_state: torch raised while reading the generator state')
+    return int(out[0]) & (2 ** 64 - 1), int(out[1]) & (2 ** 64 - 1), int(out[2]), int(out[3])
 
 
 def check(rc):

@@ -1,0 +1,76 @@
+// bl_rand.hip -- bl_rand_block: the T-1 descend uniforms of a move as ONE launch, stream-identical to the reference's protocol.
+//
+// The reference's descend draws `at::rand_like(logits.select(2, 0))` -- a (B,T) f16 tensor -- from torch's generator once per
+// simulation (boardlaw/mcts/cpp/cuda.cu:191).  On the device that is torch's grid-stride Philox kernel
+// (ATen/native/cuda/DistributionTemplates.h: distribution_elementwise_grid_stride_kernel + uniform_kernel):
+//     thread idx < threads draws, in loop l, the Philox4x32-10 block of  key = seed,  counter = {offset/4 + l  (low 64 bits),
+//     idx (high 64 bits)}  and writes component j to element idx + threads*(4l + j) (if < numel) as
+//     f16(2^-32 + float(u) * 2^-32), with 1.0 mapped to 0 (curand's (0,1] turned into [0,1));
+//     the generator's offset then advances by 4*loops.
+// Call c of a move therefore sees offset + c*4*loops, and all n_calls calls are one grid here: same seed, same counters, same
+// conversion -- the same bits (tests/test_rng_stream.py compares the block with n_calls stacked torch.rand_like tensors on the
+// device, and a whole seeded search under MoveRng with the same search under TorchRng).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/boardlaw_amd.h"
+#include "bl_device.h"
+
+namespace bl {
+
+__device__ __forceinline__ uint4 philox4x32_10(uint4 c, uint2 k) {
+#pragma unroll
+    for (int r = 0; r < 10; r++) {
+        const unsigned long long m0 = (unsigned long long)0xD2511F53u * c.x, m1 = (unsigned long long)0xCD9E8D57u * c.z;
+        c = uint4{(unsigned)(m1 >> 32) ^ c.y ^ k.x, (unsigned)m1, (unsigned)(m0 >> 32) ^ c.w ^ k.y, (unsigned)m0};
+        k.x += 0x9E3779B9u; k.y += 0xBB67AE85u;
+    }
+    return c;
+}
+
+// hiprand_uniform (rocrand_uniform.h: uniform_distribution) then torch's uniform_kernel for Half with from = 0, to = 1
+__device__ __forceinline__ uint16_t uniform_f16(unsigned int u) {
+    const float r = 2.3283064365386963e-10f + (float)u * 2.3283064365386963e-10f;
+    const uint16_t h = f2h(r);
+    return h == 0x3c00u ? (uint16_t)0 : h;
+}
+
+__global__ void __launch_bounds__(256) rand_block_kernel(uint16_t* out, int n_calls, long numel, long threads, int loops,
+                                                         unsigned long long seed_or_ptr, unsigned long long offset_or_ptr,
+                                                         unsigned int intragraph, int captured) {
+    // at::cuda::philox::unpack
+    unsigned long long seed = seed_or_ptr, offset = offset_or_ptr;
+    if (captured) {
+        seed = (unsigned long long)*(const long long*)seed_or_ptr;
+        offset = (unsigned long long)*(const long long*)offset_or_ptr + intragraph;
+    }
+    const long per_call = threads * loops;
+    const long total = per_call * n_calls;
+    for (long g = (long)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (long)gridDim.x * blockDim.x) {
+        const long c = g / per_call, rem = g - c * per_call;
+        const long l = rem / threads, idx = rem - l * threads;
+        const unsigned long long ctr = offset / 4 + (unsigned long long)c * loops + l;
+        const uint4 r = philox4x32_10(uint4{(unsigned)ctr, (unsigned)(ctr >> 32), (unsigned)idx, (unsigned)((unsigned long long)idx >> 32)},
+                                      uint2{(unsigned)seed, (unsigned)(seed >> 32)});
+        uint16_t* dst = out + c * numel;
+        const long li = idx + threads * 4 * l;
+        if (li < numel) dst[li] = uniform_f16(r.x);
+        if (li + threads < numel) dst[li + threads] = uniform_f16(r.y);
+        if (li + 2 * threads < numel) dst[li + 2 * threads] = uniform_f16(r.z);
+        if (li + 3 * threads < numel) dst[li + 3 * threads] = uniform_f16(r.w);
+    }
+}
+
+}  // namespace bl
+
+extern "C" int bl_rand_block(void* out, int n_calls, long numel, long threads, int loops, unsigned long long seed_or_ptr,
+                             unsigned long long offset_or_ptr, unsigned int offset_intragraph, int captured, bl_stream_t stream) {
+    if (!out || n_calls <= 0 || numel <= 0 || threads <= 0 || threads % 256 != 0 || loops <= 0) return BL_EINVAL;
+    if ((long)loops * threads * 4 < numel || (long)(loops - 1) * threads * 4 >= numel) return BL_EINVAL;     // loops = (numel-1)/(4*threads)+1
+    if (captured && (!seed_or_ptr || !offset_or_ptr)) return BL_EINVAL;
+    const long total = threads * loops * (long)n_calls;
+    long blocks = (total + 255) / 256;
+    if (blocks > 65536) blocks = 65536;
+    hipLaunchKernelGGL(bl::rand_block_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (uint16_t*)out, n_calls, numel,
+                       threads, loops, seed_or_ptr, offset_or_ptr, offset_intragraph, captured);
+    return hipGetLastError() == hipSuccess ? BL_OK : BL_ELAUNCH;
+}

@@ -41,33 +41,75 @@ class TorchRng:
         return torch.distributions.Categorical(logits=logits, validate_args=False).sample()  # mcts/__init__.py:221
 
 
+def torch_rand_geometry(numel, device):
+    """(threads, loops) of torch's uniform kernel for `numel` elements on `device` (ATen/native/cuda/DistributionTemplates.h:
+    calc_execution_policy with block 256, unroll 4): what decides which Philox counter feeds which element."""
+    props = torch.cuda.get_device_properties(device)
+    grid = min(props.multi_processor_count * (props.max_threads_per_multi_processor // 256), (numel + 255) // 256)
+    threads = 256 * grid
+    return threads, (numel - 1) // (4 * threads) + 1
+
+
 class MoveRng(TorchRng):
-    """Same draws from the same torch generator, but the T-1 descend uniforms of a move come from ONE rand call of shape
-    (T-1, B, T) made at the first descend instead of T-1 calls of shape (B, T).  torch's Half uniforms cost two launches
-    (float draw + cast) per call -- 6 % of a 9x9/4096-env simulation; a seeded run sees different uniforms than with
-    TorchRng (the generator is consumed in one block), which on a GPU is unobservable against the reference (its CUDA
-    stream differs per device anyway).  Opt-in: MCTS(..., rng=MoveRng())."""
+    """The reference's random draws from the same torch generator, STREAM-IDENTICAL to TorchRng -- same seed, same numbers, same
+    generator offset afterwards -- with the T-1 descend uniforms of a move produced by ONE launch (bl_rand_block) instead of T-1
+    `rand_like` calls: the kernel evaluates the Philox counters those calls would have used (call c of the move sees the
+    generator offset advanced by c calls) and the generator is advanced by what they would have consumed.  The Dirichlet and the
+    Categorical draw stay torch's own.  Shapes the block cannot serve (non-f16, CPU) fall back to `rand_like` call by call.
+    tests/test_rng_stream.py: the block equals the stacked rand_like tensors, and a seeded search is the TorchRng search."""
 
     def __init__(self, generator=None):
         """generator: a torch.Generator on the search's device, or None for torch's default one.  Searches that replay
         captured moves CONCURRENTLY (several actors on one GPU, each on its own stream) need a generator each: a captured
         graph reads its Philox offset from a tensor the generator owns and refills before every replay, so two graphs on
         one generator race for it (and, being the same graph, would draw the same numbers)."""
-        self.block, self.i, self.generator = None, 0, generator
+        self.block, self.i, self.generator, self.expected = None, 0, generator, 0
 
-    def start(self, n_calls, like):
-        self.block = torch.rand((n_calls,) + tuple(like.shape), dtype=like.dtype, device=like.device, generator=self.generator)
-        self.i = 0
+    def start(self, n_calls, like=None):
+        """Announces that `n_calls` rand_like draws of one shape follow (a move's descents).  Nothing is drawn yet: the
+        reference's Dirichlet comes first in the stream (MCTS.initialize), the block is cut at the first rand_like."""
+        self.block, self.i, self.expected = None, 0, n_calls
+
+    def _draw_block(self, x):
+        threads, loops = torch_rand_geometry(x.numel(), x.device)
+        gen = self.generator if self.generator is not None else torch.cuda.default_generators[x.device.index if x.device.index is not None else torch.cuda.current_device()]
+        with torch.cuda.device(x.device):
+            seed, offset, intragraph, captured = _native.philox_state(gen, self.expected * 4 * loops)
+            block = torch.empty((self.expected,) + tuple(x.shape), dtype=torch.half, device=x.device)
+            _native.check(_native.lib().bl_rand_block(block.data_ptr(), self.expected, x.numel(), threads, loops, seed, offset, intragraph,
+                                                      captured, _native.stream(x.device)))
+        return block
 
     def rand_like(self, x):
+        if self.block is None and self.expected > 0 and x.is_cuda and x.dtype == torch.half:
+            self.block, self.i = self._draw_block(x), 0
         if self.block is None or self.i >= self.block.shape[0] or self.block.shape[1:] != x.shape:
             return torch.rand(x.shape, dtype=x.dtype, device=x.device, generator=self.generator)
         r = self.block[self.i]
         self.i += 1
+        if self.i == self.block.shape[0]:
+            self.expected = 0
         return r
 
-    # The two per-move draws, each as ONE launch of torch's generator plus the library (same distributions as the
-    # reference's calls, fewer kernels; TorchRng keeps torch.distributions for both):
+    def dirichlet(self, alpha, shape):
+        # torch.distributions.Dirichlet(alpha).sample(shape) with this rng's generator: the same three kernels (gamma
+        # variates, their sum, the clamped quotient -- ATen's _sample_dirichlet), the same use of the generator
+        return torch._sample_dirichlet(alpha.expand(*shape, alpha.shape[-1]), self.generator)
+
+    def categorical(self, logits):
+        if self.generator is None:
+            return super().categorical(logits)
+        # Categorical(logits=...).sample() with a private generator: what torch.distributions does (normalise, softmax,
+        # multinomial of one draw with replacement), the generator passed through
+        probs = torch.softmax(logits - logits.logsumexp(-1, keepdim=True), -1)
+        return torch.multinomial(probs.reshape(-1, probs.shape[-1]), 1, True, generator=self.generator).reshape(probs.shape[:-1])
+
+
+class FastRng(MoveRng):
+    """MoveRng with the two per-move draws as ONE generator launch each plus the library -- the same distributions as the
+    reference's calls, NOT its stream (a seeded run sees different numbers than TorchRng/MoveRng): opt-in, for throughput
+    studies only."""
+
     def gamma(self, alpha, shape):
         """Unnormalised Dirichlet draw: the Gamma(alpha, 1) variates torch's Dirichlet sampler starts from
         (torch._sample_dirichlet = standard_gamma / sum).  bl_sim_plant_root normalises over the valid actions anyway
@@ -367,7 +409,7 @@ def mcts(worlds, network, **kwargs):
     kwargs.setdefault('obs_half', bool(getattr(network, 'wants_half_obs', False)))
     m = MCTS(worlds, **kwargs)
     if hasattr(m.rng, 'start') and m.n_nodes > 1:
-        m.rng.start(m.n_nodes - 1, m.decisions.logits[:, :, 0])
+        m.rng.start(m.n_nodes - 1)          # announces the move's T-1 descend draws; drawn after the root's Dirichlet
     if hasattr(network, 'refresh_if_stale') and not (worlds.device.type == 'cuda' and torch.cuda.is_current_stream_capturing()):
         network.refresh_if_stale()     # picks up optimiser steps; a captured move is refreshed by its replayer instead
     m.initialize(network)

@@ -241,6 +241,19 @@ int bl_fold_variant(void);   /* 1: one-wait-state fold in use; 0: ISA-padded fol
 int bl_draw_actions(const void* probs /*f16 (B,A)*/, const float* uniforms /*(B)*/, long long* actions_out /*i64 (B)*/,
                     int B, int A, bl_stream_t stream);
 
+/* The T-1 descend uniforms of one move as ONE launch, bit for bit what n_calls consecutive `at::rand_like` calls on a
+ * (numel,) f16 tensor draw from a torch generator on this device (boardlaw/mcts/cpp/cuda.cu:191; torch's kernel:
+ * ATen/native/cuda/DistributionTemplates.h, distribution_elementwise_grid_stride_kernel + uniform_kernel).  Call c, thread
+ * idx < threads, loop l < loops evaluates Philox4x32-10 with key = seed and counter = {offset/4 + c*loops + l, idx}; component j
+ * goes to element idx + threads*(4l + j) of call c as f16(2^-32 + float(u)*2^-32), 1.0 mapped to 0.  `threads` and `loops` are
+ * torch's launch geometry for numel elements on the device: threads = 256 * min(CUs * (max threads per CU / 256),
+ * ceil(numel / 256)), loops = (numel - 1) / (4 * threads) + 1 (BL_EINVAL if inconsistent); the caller advances the generator by
+ * n_calls * 4 * loops.  captured != 0: seed_or_ptr / offset_or_ptr are DEVICE POINTERS to int64 (what torch's generator hands
+ * kernels during HIP-graph capture) and offset_intragraph is added to the loaded offset; else they are the values. */
+int bl_rand_block(void* out /*f16 (n_calls, numel)*/, int n_calls, long numel, long threads, int loops,
+                  unsigned long long seed_or_ptr, unsigned long long offset_or_ptr, unsigned int offset_intragraph, int captured,
+                  bl_stream_t stream);
+
 /* Up to BL_COPY_MAX device-to-device copies in ONE launch (`items` is HOST memory, read before the call returns).  Copy k
  * moves `rows` rows of `row_bytes` bytes; row r starts at src + r*src_pitch and dst + r*dst_pitch (rows == 1: a flat copy,
  * pitches ignored).  What replaces the reference's `decisions.clone()` / `arrdict.clone()` (mcts/__init__.py:229,

@@ -396,16 +396,195 @@ def gen_snapshot(mcts_mod, hex_, networks, out):
     print('snapshot', sorted(agent.state_dict())[:3], '...')
 
 
+# --------------------------------------------------------------------------------------------------------------
+# 7. A search whose network is as wide as the bench's (BEST row of boardlaw/main.py:17-25: 9x9 -> 512x4), so that the
+#    fused MFMA kernels (bl_mlp_forward_f16 / bl_sim_infer_finish, W >= 256) meet outputs the reference recorded
+# --------------------------------------------------------------------------------------------------------------
+def gen_search_wide(mcts_mod, hex_, networks, mcuda, out):
+    res, _ = run_search_fixture(mcts_mod, hex_, networks, mcuda, 9, 64, 64, 512, 4, 1, 15, set(), 27)
+    # the leaf worlds can be rebuilt from the tree's boards; keep the file small
+    for k in [k for k in res if k.endswith('net_board')]:
+        del res[k]
+    np.savez_compressed(os.path.join(out, 'search_9x9_w512.npz'), **res)
+    print('search_9x9_w512', os.path.getsize(os.path.join(out, 'search_9x9_w512.npz')) // 1024, 'KiB')
+
+
+# --------------------------------------------------------------------------------------------------------------
+# 8. Arena (boardlaw/arena/common.py:75-106 `evaluate`, arena/neural.py:46-200 `Tracker`/`ChunkEvaluator`/`evaluate_chunk`)
+#    with deterministic agents from seeded mid-game positions.  The arena modules import the reference's run-directory,
+#    SQL and Elo layers at module level (never used by these functions): those are replaced by empty stub modules.
+#    numpy >= 2 dropped `np.math`, which common.py:80 uses: it is pointed at the stdlib module for the call.
+# --------------------------------------------------------------------------------------------------------------
+class _Stub(types.ModuleType):
+    def __getattr__(self, k):
+        if k.startswith('__'):
+            raise AttributeError(k)
+        return _Stub(self.__name__ + '.' + k)
+
+
+def import_reference_arena():
+    import math
+    for name in ('pavlov.storage', 'pavlov.runs', 'boardlaw.sql', 'boardlaw.backup', 'boardlaw.elos', 'boardlaw.arena.live',
+                 'boardlaw.arena.mohex', 'rebar.parallel'):
+        sys.modules[name] = _Stub(name)
+    import pavlov, boardlaw
+    pavlov.storage, pavlov.runs = sys.modules['pavlov.storage'], sys.modules['pavlov.runs']
+    boardlaw.sql, boardlaw.backup, boardlaw.elos = sys.modules['boardlaw.sql'], sys.modules['boardlaw.backup'], sys.modules['boardlaw.elos']
+    sys.modules.pop('boardlaw.arena', None)         # gen_rollout may have put a stub there
+    if not hasattr(np, 'math'):
+        np.math = math
+    import boardlaw.arena.common as common
+    import boardlaw.arena.neural as neural
+    return common, neural
+
+
+def premixed_worlds(hex_, n_envs, S, moves, seed):
+    """Seeded mid-game positions: env e has played between 0 and `moves` uniformly random legal moves."""
+    torch.manual_seed(seed)
+    worlds = hex_.Hex.initial(n_envs, S, device='cpu')
+    upto = torch.randint(moves + 1, (n_envs,))
+    for k in range(moves):
+        actions = torch.distributions.Categorical(probs=worlds.valid.float()).sample()
+        stepped, trans = worlds.step(actions)
+        go = (upto > k) & ~trans.terminal
+        worlds[go] = stepped[go]
+    return worlds
+
+
+def gen_arena(hex_, out):
+    common, neural = import_reference_arena()
+    import pandas as pd
+    res = {}
+    for S, n_envs in ((5, 64), (7, 2048), (9, 2048), (11, 2048)):
+        start = premixed_worlds(hex_, n_envs, S, S * S // 3, 500 + S)
+        res[f'S{S}_board'] = np_(start.board); res[f'S{S}_seats'] = np_(start.seats)
+        agents = {'front': EdgeAgent(False, 1), 'back': EdgeAgent(True, 0)}
+        results = common.evaluate(start.clone(), agents)
+        for i, r in enumerate(results):
+            res[f'S{S}_r{i}_names'] = np.array(r.names)
+            res[f'S{S}_r{i}_wins'] = np.array(r.wins); res[f'S{S}_r{i}_moves'] = np.array(r.moves); res[f'S{S}_r{i}_games'] = np.array(r.games)
+        print('arena', S, [(r.names, r.wins, r.moves) for r in results])
+    # ChunkEvaluator: three deterministic agents, all ordered pairs, with some games already played
+    names = ['a', 'b', 'c']
+    agents = {'a': EdgeAgent(False, 0), 'b': EdgeAgent(True, 1), 'c': EdgeAgent(False, 2)}
+    games = pd.DataFrame([[0, 3, 0], [1, 0, 5], [0, 2, 0]], names, names)
+    for S in (5, 9):
+        n_envs_per = 8
+
+        def worldfunc(n_envs, S=S):
+            return premixed_worlds(hex_, n_envs, S, S * S // 3, 600 + S)
+        ev = neural.ChunkEvaluator(worldfunc, agents, games.copy(), n_envs_per=n_envs_per, device='cpu')
+        res[f'chunk{S}_board'] = np_(ev.worlds.board); res[f'chunk{S}_seats'] = np_(ev.worlds.seats)
+        res[f'chunk{S}_live'] = np_(ev.tracker.live)
+        results, picks = [], []
+        while not ev.finished():
+            name, mask, live = ev.tracker.suggest(ev.worlds.seats)
+            picks.append((names.index(name), int(mask.sum())))
+            results.extend(ev.step())
+        res[f'chunk{S}_picks'] = np.array(picks)
+        res[f'chunk{S}_games'] = games.values
+        res[f'chunk{S}_names'] = np.array([r.names for r in results])
+        res[f'chunk{S}_wins'] = np.array([r.wins for r in results]); res[f'chunk{S}_moves'] = np.array([r.moves for r in results])
+        # the evaluator's own tallies at the end (reported pairs are marked -1, arena/neural.py:160): covers the pairs that
+        # started with games already played, which the reference never reports (their wins never sum to n_envs_per)
+        res[f'chunk{S}_final_wins'] = np_(ev.stats.wins); res[f'chunk{S}_final_moves'] = np_(ev.stats.moves)
+        print('chunk', S, len(picks), 'steps', [(r.names, r.wins, r.moves) for r in results])
+    np.savez_compressed(os.path.join(out, 'arena.npz'), **res)
+
+
+# --------------------------------------------------------------------------------------------------------------
+# 9. The learner (boardlaw/main.py:61-74 `as_chunk`, :76-98 `optimize`) on a buffer of real self-play (reference
+#    MCTSAgent on its CPU path), CPU f32 (GradScaler and autocast disable themselves without a GPU).  main.py imports the
+#    run-directory/stats layer (pavlov) at module level; it is replaced by a stub whose `stats` records what
+#    `optimize` reports (`loss.value`, `loss.policy`).
+# --------------------------------------------------------------------------------------------------------------
+def import_reference_main(recorded):
+    stats = types.ModuleType('pavlov.stats')
+
+    @contextlib.contextmanager
+    def defer():
+        yield None
+    stats.defer = defer
+
+    def record(name, *args, **kwargs):
+        recorded.setdefault(name, []).append([a.detach().clone() if torch.is_tensor(a) else a for a in args])
+    for fn in ('mean', 'rate', 'cumsum', 'max', 'gpu'):
+        setattr(stats, fn, record)
+    import pavlov
+    pavlov.stats = stats
+    sys.modules['pavlov.stats'] = stats
+    for name in ('pavlov.logs', 'pavlov.runs', 'pavlov.storage', 'pavlov.archive', 'boardlaw.arena', 'boardlaw.storage', 'boardlaw.noisescales'):
+        sys.modules[name] = _Stub(name)
+        parent, _, leaf = name.rpartition('.')
+        setattr(sys.modules[parent], leaf, sys.modules[name])
+    import boardlaw.main as main
+    return main
+
+
+def gen_learner(mcts_mod, hex_, networks, out):
+    import warnings
+    from rebar import arrdict
+    import boardlaw.learning as learning
+    recorded = {}
+    main = import_reference_main(recorded)
+    res = {}
+    S, B, T_buf, nodes, width, depth = 5, 16, 8, 16, 16, 3
+    torch.manual_seed(41)
+    worlds = premixed_worlds(hex_, B, S, 6, 42)
+    net = networks.FCModel(worlds.obs_space, worlds.action_space, width=width, depth=depth)
+    with torch.no_grad():
+        for p in net.parameters():
+            if p.ndim == 0:
+                p.fill_(0.3)
+    agent = mcts_mod.MCTSAgent(net, n_nodes=nodes)
+    buffer = []
+    for _ in range(T_buf):                                   # main.py:172-186
+        with torch.no_grad():
+            decisions = agent(worlds, value=True)
+        new_worlds, transition = worlds.step(decisions.actions)
+        buffer.append(arrdict.arrdict(worlds=worlds, decisions=decisions.half(), transitions=learning.half(transition)).detach())
+        worlds = new_worlds
+    stacked = arrdict.stack(buffer)
+    res['meta'] = np.array([S, B, T_buf, nodes, width, depth], np.int64)
+    res['buf_board'] = np_(stacked.worlds.board); res['buf_seats'] = np_(stacked.worlds.seats)
+    for k in ('logits', 'prior', 'v', 'n_sims', 'n_leaves', 'actions'):
+        res['buf_dec_' + k] = np_(stacked.decisions[k])
+    res['buf_rewards'] = np_(stacked.transitions.rewards); res['buf_terminal'] = np_(stacked.transitions.terminal)
+    for k, v in net.state_dict().items():
+        res['net_state::' + k] = np_(v)
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        chunk, rest = main.as_chunk(buffer, B * 3)           # batch_size 3B: the three oldest steps are dropped
+        res['reward_to_go'] = np_(chunk.reward_to_go); res['rest_len'] = np.array(len(rest))
+        opt = torch.optim.Adam(net.parameters(), lr=1e-3)
+        scaler = torch.cuda.amp.GradScaler()
+        torch.manual_seed(43)
+        idxs = (torch.randint(T_buf, (B,)), torch.arange(B))  # main.py:168
+        res['idx_t'] = np_(idxs[0])
+        for step in range(3):
+            main.optimize(net, scaler, opt, chunk[idxs])
+            res[f'step{step}_policy_loss'] = np_(recorded['loss.policy'][-1][0]); res[f'step{step}_value_loss'] = np_(recorded['loss.value'][-1][0])
+            for k, v in net.state_dict().items():
+                res[f'step{step}_state::' + k] = np_(v)
+    np.savez_compressed(os.path.join(out, 'learner_5x5.npz'), **res)
+    print('learner', {k: float(res[k]) for k in res if k.endswith('_loss')})
+
+
 if __name__ == '__main__':
+    only = set(sys.argv[1:])          # e.g. `make_golden.py arena learner wide`: only those; no arguments: everything
+    want = lambda name: not only or name in only
     mcts_mod, hex_, networks, validation, mcuda, hcuda = import_reference()
     out = HERE if not VARIANT else os.path.join('/tmp', 'golden' + VARIANT)
     os.makedirs(out, exist_ok=True)
-    gen_hex(hex_, hcuda.module(), out)
-    gen_search(mcts_mod, hex_, networks, mcuda, out)
-    gen_toy(mcts_mod, validation, out)
-    gen_exp(out)
-    gen_snapshot(mcts_mod, hex_, networks, out)
-    gen_rollout(hex_, out)
+    if want('hex'): gen_hex(hex_, hcuda.module(), out)
+    if want('search'): gen_search(mcts_mod, hex_, networks, mcuda, out)
+    if want('wide'): gen_search_wide(mcts_mod, hex_, networks, mcuda, out)
+    if want('toy'): gen_toy(mcts_mod, validation, out)
+    if want('exp'): gen_exp(out)
+    if want('snapshot'): gen_snapshot(mcts_mod, hex_, networks, out)
+    if want('learner'): gen_learner(mcts_mod, hex_, networks, out)
+    if want('arena'): gen_arena(hex_, out)
+    if want('rollout'): gen_rollout(hex_, out)
 
 
 # tests/golden/learning.npz: produced by calling the reference's boardlaw.learning.reward_to_go / present_value on seeded

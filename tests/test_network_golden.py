@@ -164,3 +164,36 @@ def test_gpu_network_against_reference_outputs(name):
         assert np.array_equal(got16 != 0xfc00, fin16)
         d16 = ulp16(got16[fin16], want16[fin16])
         assert (d16 <= 3).mean() >= 0.99 and d16.max() <= 16, (d16.max(), (d16 <= 3).mean())
+
+
+@pytest.mark.gpu
+def test_plant_root_gamma_route_equals_dirichlet_route():
+    """FastRng hands bl_sim_plant_root the UNNORMALISED Gamma(alpha) variates; TorchRng / MoveRng hand it torch's Dirichlet draw
+    (the same variates divided by their sum and clamped).  plant_root renormalises over the valid actions either way
+    (mcts/__init__.py:19-22), so the stored root rows may differ only by the rounding of the intermediate quotient: within 1 f16
+    ulp, identical -inf pattern, identical kept-action lists."""
+    from boardlaw_amd import networks
+    from boardlaw_amd.hex import Hex
+    from boardlaw_amd.mcts import MCTS
+    torch.manual_seed(0)
+    B, S = 2048, 9
+    gen = torch.Generator(device='cuda'); gen.manual_seed(5)
+    world = Hex.initial(B, S)
+    for _ in range(27):
+        v = world.valid
+        world, _ = world.step((torch.rand(v.shape, device='cuda', generator=gen) * v).argmax(-1), check=False)
+    net = networks.Inference(networks.FCModel(world.obs_space, world.action_space, width=256, depth=2).cuda(), fused=True)
+    gamma = torch._standard_gamma(torch.full((B, S * S), 10 / (S * S), device='cuda'))
+    dirichlet = (gamma / gamma.sum(-1, keepdim=True)).clamp(torch.finfo(torch.float).tiny, 1 - torch.finfo(torch.float).eps)
+
+    rows = []
+    for draw in (gamma, dirichlet):
+        m = MCTS(world, n_nodes=4, rng=FixedDraw(draw))
+        m.initialize(net)
+        rows.append((f16bits(m.decisions.logits[:, 0]), m._nk[:, 0].cpu().numpy(), (m._cca[:, 0].cpu().numpy().view(np.uint32) & 0xffff)))
+    (la, nka, ca), (lb, nkb, cb) = rows
+    inf = la == 0xfc00
+    assert np.array_equal(inf, lb == 0xfc00) and np.array_equal(nka, nkb)
+    assert ulp16(la[~inf], lb[~inf]).max() <= 1
+    for b in range(0, B, 97):
+        assert np.array_equal(ca[b, :nka[b]], cb[b, :nkb[b]])

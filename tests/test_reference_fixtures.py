@@ -1,0 +1,292 @@
+"""Round-3 reference fixtures (tests/golden/make_golden.py: gen_arena, gen_learner, gen_search_wide), all produced by
+RUNNING THE REFERENCE:
+
+  * arena.npz          boardlaw/arena/common.py:75-106 `evaluate` at 5x5/64 and 7x7, 9x9, 11x11 with 2048 envs (config 5's shape)
+                       and arena/neural.py:46-200 `ChunkEvaluator` on 5x5 / 9x9, deterministic agents, seeded mid-game positions;
+  * learner_5x5.npz    boardlaw/main.py:61-74 `as_chunk` and :76-98 `optimize` (three Adam steps) on a buffer of the reference's
+                       own self-play;
+  * search_9x9_w512.npz a whole reference search whose network is the bench's 512x4 (main.py:24), so that the fused MFMA kernels
+                       meet outputs the reference recorded.
+
+CPU tests run the host logic on a test-only Hex world whose board dynamics are the oracle's; the -m gpu tests run the product's
+Hex (HIP kernels) and networks."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+
+
+def _gold(name):
+    return np.load(os.path.join(GOLD, name))
+
+
+class EdgeAgent:
+    """The deterministic fixture agent of make_golden.py: plays the k-th legal cell from the front (or back)."""
+
+    def __init__(self, from_end, k=0):
+        self.from_end, self.k = from_end, k
+
+    def __call__(self, world, **kwargs):
+        from boardlaw_amd import arrdict
+        valid = world.valid
+        order = valid.int().cumsum(-1) if not self.from_end else valid.int().flip(-1).cumsum(-1).flip(-1)
+        want = torch.minimum(torch.full_like(order[:, :1], self.k + 1), valid.sum(-1, keepdim=True))
+        hit = ((order == want) & valid).int()
+        actions = hit.argmax(-1) if not self.from_end else valid.shape[-1] - 1 - hit.flip(-1).argmax(-1)
+        return arrdict.arrdict(actions=actions, v=world.seats.float() + .5, count=valid.sum(-1).int())
+
+
+def oracle_hex(orc):
+    """A CPU stand-in for boardlaw_amd.hex.Hex: same arrdict type and surface, board dynamics from the oracle (TEST ONLY)."""
+    from boardlaw_amd import arrdict
+    from boardlaw_amd.hex import Hex
+
+    class OracleHex(Hex):
+        def _observe(self):
+            b = np.ascontiguousarray(self.board.numpy()); s = np.ascontiguousarray(self.seats.numpy().astype(np.int32))
+            lead = b.shape[:-2]
+            obs = orc.hex_observe(b.reshape(-1, *b.shape[-2:]), s.reshape(-1))
+            self._obs = torch.from_numpy(obs.reshape(*lead, *obs.shape[1:]))
+
+        def step(self, actions, reset=True, check=True):
+            assert reset
+            nb, ns, rewards, term = orc.hex_world_step(np.ascontiguousarray(self.board.numpy()), np.ascontiguousarray(self.seats.numpy().astype(np.int32)),
+                                                       np.ascontiguousarray(actions.numpy().astype(np.int32)))
+            return type(self)(board=torch.from_numpy(nb), seats=torch.from_numpy(ns)), \
+                arrdict.arrdict(terminal=torch.from_numpy(term).bool(), rewards=torch.from_numpy(rewards))
+    return OracleHex
+
+
+# ---------------------------------------------------------------------------------------------------------------- arena
+def _check_evaluate(g, S, kind, device):
+    from boardlaw_amd import arena
+    worlds = kind(board=torch.from_numpy(g[f'S{S}_board']).to(device), seats=torch.from_numpy(g[f'S{S}_seats']).to(device))
+    results = arena.evaluate(worlds, {'front': EdgeAgent(False, 1), 'back': EdgeAgent(True, 0)})
+    assert len(results) == 2
+    for i, r in enumerate(results):
+        assert tuple(r.names) == tuple(str(x) for x in g[f'S{S}_r{i}_names']), (S, i)
+        assert tuple(r.wins) == tuple(g[f'S{S}_r{i}_wins'].tolist()), (S, i, r.wins)
+        assert r.moves == float(g[f'S{S}_r{i}_moves']) and r.games == float(g[f'S{S}_r{i}_games']), (S, i)
+        assert r.boardsize == S
+
+
+def _check_chunk_evaluator(g, S, kind, device):
+    import pandas as pd
+    from boardlaw_amd import arena
+    names = ['a', 'b', 'c']
+    agents = {'a': EdgeAgent(False, 0), 'b': EdgeAgent(True, 1), 'c': EdgeAgent(False, 2)}
+    games = pd.DataFrame(g[f'chunk{S}_games'], names, names)
+    start = kind(board=torch.from_numpy(g[f'chunk{S}_board']).to(device), seats=torch.from_numpy(g[f'chunk{S}_seats']).to(device))
+    ev = arena.ChunkEvaluator(lambda n: start.clone(), agents, games, n_envs_per=8, device=device)
+    assert np.array_equal(ev.tracker.live.cpu().numpy(), g[f'chunk{S}_live'])
+    results, picks = [], []
+    while not ev.finished():
+        name, mask, _ = ev.tracker.suggest(ev.worlds.seats)
+        picks.append((names.index(name), int(mask.sum())))
+        results.extend(ev.step())
+    assert np.array_equal(np.array(picks), g[f'chunk{S}_picks']), 'the dispatch order (agent, mask size per step) differs'
+    assert [tuple(r.names) for r in results] == [tuple(x) for x in g[f'chunk{S}_names'].tolist()]
+    assert np.array_equal(np.array([r.wins for r in results]), g[f'chunk{S}_wins'])
+    assert np.array_equal(np.array([r.moves for r in results]), g[f'chunk{S}_moves'])
+    assert np.array_equal(ev.wins.cpu().numpy(), g[f'chunk{S}_final_wins']) and np.array_equal(ev.moves.cpu().numpy(), g[f'chunk{S}_final_moves'])
+
+
+@pytest.mark.parametrize('S', [5, 7])
+def test_arena_evaluate_matches_reference_cpu(oracle, S):
+    _check_evaluate(_gold('arena.npz'), S, oracle_hex(oracle), 'cpu')
+
+
+@pytest.mark.parametrize('S', [5, 9])
+def test_chunk_evaluator_matches_reference_cpu(oracle, S):
+    _check_chunk_evaluator(_gold('arena.npz'), S, oracle_hex(oracle), 'cpu')
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('S', [5, 7, 9, 11])
+def test_arena_evaluate_matches_reference_gpu(S):
+    """config 5's shape -- 2048 envs per board size through arena.evaluate's masked variable-size calls -- on the product's Hex."""
+    from boardlaw_amd.hex import Hex
+    _check_evaluate(_gold('arena.npz'), S, Hex, 'cuda')
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('S', [5, 9])
+def test_chunk_evaluator_matches_reference_gpu(S):
+    from boardlaw_amd.hex import Hex
+    _check_chunk_evaluator(_gold('arena.npz'), S, Hex, 'cuda')
+
+
+# -------------------------------------------------------------------------------------------------------------- learner
+def _learner_setup(g, kind, device):
+    from boardlaw_amd import arrdict, networks, heads
+    S, B, T_buf, nodes, width, depth = (int(x) for x in g['meta'])
+    half = lambda k: torch.from_numpy(g[k].view(np.int16)).view(torch.half)
+    buffer = []
+    for t in range(T_buf):
+        worlds = kind(board=torch.from_numpy(g['buf_board'][t]), seats=torch.from_numpy(g['buf_seats'][t]))
+        decisions = arrdict.arrdict(logits=half('buf_dec_logits')[t], prior=half('buf_dec_prior')[t], v=half('buf_dec_v')[t],
+                                    # main.py:183 stores `decisions.half()`: the integer fields are f16 in the buffer, too
+                                    n_sims=half('buf_dec_n_sims')[t], n_leaves=half('buf_dec_n_leaves')[t], actions=half('buf_dec_actions')[t])
+        transitions = arrdict.arrdict(rewards=half('buf_rewards')[t], terminal=torch.from_numpy(g['buf_terminal'][t]).bool())
+        buffer.append(arrdict.arrdict(worlds=worlds, decisions=decisions, transitions=transitions).to(device))
+    net = networks.FCModel(heads.Tensor((S, S, 2)), heads.Masked(S * S), width=width, depth=depth)
+    sd = {k[len('net_state::'):]: torch.from_numpy(np.array(g[k])) for k in g.files if k.startswith('net_state::')}
+    net.load_state_dict(sd, strict=True)
+    idxs = (torch.from_numpy(g['idx_t']).to(device), torch.arange(B, device=device))
+    return buffer, net.to(device), idxs, B
+
+
+def test_as_chunk_and_optimize_match_reference_cpu(oracle):
+    """training.as_chunk / training.optimize against the reference's main.as_chunk / main.optimize on the same recorded
+    self-play buffer, CPU f32: reward-to-go targets, both losses and every parameter after each of three Adam steps, bit for bit."""
+    from boardlaw_amd import training
+    g = _gold('learner_5x5.npz')
+    buffer, net, idxs, B = _learner_setup(g, oracle_hex(oracle), 'cpu')
+    chunk, rest = training.as_chunk(buffer, 3 * B)
+    assert len(rest) == int(g['rest_len'])
+    assert np.array_equal(chunk.reward_to_go.view(torch.int16).numpy().view(np.uint16), g['reward_to_go'])
+    opt = torch.optim.Adam(net.parameters(), lr=1e-3)
+    scaler = torch.amp.GradScaler('cuda', enabled=False)
+    for step in range(3):
+        pl, vl = training.optimize(net, scaler, opt, chunk[idxs], sync_gradients=False)
+        assert np.array_equal(pl.numpy().view(np.uint32), g[f'step{step}_policy_loss'].view(np.uint32)), (step, float(pl))
+        assert np.array_equal(vl.numpy().view(np.uint32), g[f'step{step}_value_loss'].view(np.uint32)), (step, float(vl))
+        for k, v in net.state_dict().items():
+            assert np.array_equal(v.numpy().view(np.uint32), g[f'step{step}_state::' + k].view(np.uint32)), (step, k)
+
+
+@pytest.mark.gpu
+def test_learner_step_on_gpu_against_reference_numbers():
+    """The same three steps on the GPU under AMP (the reference's GPU configuration: autocast + GradScaler, main.py:78,93-95)
+    against the numbers the reference's CPU f32 run recorded -- not against this repo's own CPU run.  Tolerances: losses within
+    2e-3 relative (f16 autocast forward); parameters within 1.5e-3 absolute after each step (lr 1e-3: Adam moves a weight by at
+    most ~lr per step, so agreement well inside k*lr means the update directions agree wherever the gradient is not tiny)."""
+    from boardlaw_amd import training
+    from boardlaw_amd.hex import Hex
+    g = _gold('learner_5x5.npz')
+    buffer, net, idxs, B = _learner_setup(g, Hex, 'cuda')
+    chunk, rest = training.as_chunk(buffer, 3 * B)
+    assert np.array_equal(chunk.reward_to_go.cpu().view(torch.int16).numpy().view(np.uint16), g['reward_to_go'])
+    opt = torch.optim.Adam(net.parameters(), lr=1e-3)
+    scaler = torch.amp.GradScaler('cuda')
+    for step in range(3):
+        pl, vl = training.optimize(net, scaler, opt, chunk[idxs], sync_gradients=False)
+        wp, wv = float(g[f'step{step}_policy_loss']), float(g[f'step{step}_value_loss'])
+        assert abs(float(pl) - wp) <= 2e-3 * abs(wp) and abs(float(vl) - wv) <= 2e-3 * max(abs(wv), 1e-3), (step, float(pl), wp, float(vl), wv)
+        for k, v in net.state_dict().items():
+            assert (v.cpu().float() - torch.from_numpy(g[f'step{step}_state::' + k])).abs().max() <= 1.5e-3, (step, k)
+
+
+# ------------------------------------------------------------------------------------------------- the 512-wide search
+def _ulp16(a_bits, b_bits):
+    def key(x):
+        x = x.astype(np.int32)
+        return np.where(x & 0x8000, -(x & 0x7fff), x & 0x7fff)
+    return np.abs(key(a_bits) - key(b_bits))
+
+
+def test_wide_fixture_network_reproduces_on_cpu(oracle):
+    """The restated FCModel with the reference's 512x4 parameters, CPU f32: the root evaluation and the first leaf
+    evaluations bit for bit (networks.py:37-40)."""
+    from test_network_golden import reference_network, f32bits, World
+    g = _gold('search_9x9_w512.npz')
+    net = reference_network(g)
+    S, B, T, width, depth, n_moves, seed = (int(x) for x in g['meta'])
+    assert (width, depth, S, T) == (512, 4, 9, 64)
+    w = World(torch.from_numpy(g['m0_net0_obs'].astype(np.float32)), torch.from_numpy(g['m0_net0_valid']).bool(), torch.from_numpy(g['m0_net0_seats']))
+    with torch.no_grad():
+        d = net(w)
+    assert np.array_equal(f32bits(d.logits), g['m0_net0_logits'].view(np.uint32)) and np.array_equal(f32bits(d.v), g['m0_net0_v'].view(np.uint32))
+
+
+@pytest.mark.gpu
+def test_fused_mfma_network_against_reference_outputs():
+    """bl_mlp_forward_f16 + bl_sim_finish's heads (networks.Inference(fused=True), the bench's network kernels) with the
+    reference's own 512x4 parameters against the f16 values the reference stored for its leaf evaluations (f32 on its CPU path,
+    then `.half()`, mcts/__init__.py:131-136).  Tolerance (fp16 autocast vs f32 -- the reference's own GPU/CPU gap): >= 99 % of
+    the finite logits within 3 f16 ulp, none beyond 16; -inf pattern identical; v within 4 f16 ulp on >= 99 %, none beyond 2^-7 abs."""
+    from test_network_golden import reference_network, f16bits
+    from boardlaw_amd import networks
+    from boardlaw_amd.hex import Hex
+    g = _gold('search_9x9_w512.npz')
+    S, B, T, width, depth, n_moves, seed = (int(x) for x in g['meta'])
+    inf = networks.Inference(reference_network(g, 'cuda'), fused=True)
+    assert inf.fused_params(B) is not None, 'the fused plan must be the one under test'
+    created = g['m0_parents'][:, 1:] != -1                       # (B, T-1): simulation s created node s
+    checked = 0
+    for sim in range(1, T):
+        rows = np.nonzero(created[:, sim - 1])[0]
+        if len(rows) == 0:
+            continue
+        world = Hex(board=torch.from_numpy(np.ascontiguousarray(g['m0_boards'][:, sim])).cuda(),
+                    seats=torch.from_numpy(np.ascontiguousarray(g['m0_seats'][:, sim])).cuda().int())
+        with torch.no_grad():
+            d = inf(world)
+        want_l, want_v = g['m0_tree_logits'][rows, sim], g['m0_tree_v'][rows, sim]
+        got_l, got_v = f16bits(d.logits)[rows], f16bits(d.v)[rows]
+        fin = want_l != 0xfc00
+        assert np.array_equal(got_l != 0xfc00, fin), sim
+        dl = _ulp16(got_l[fin], want_l[fin])
+        assert (dl <= 3).mean() >= 0.99 and dl.max() <= 16, (sim, dl.max(), (dl <= 3).mean())
+        dv = _ulp16(got_v, want_v)
+        fv = lambda bits: torch.from_numpy(bits.view(np.int16)).view(torch.half).float().numpy()
+        assert (dv <= 4).mean() >= 0.99 and np.abs(fv(got_v) - fv(want_v)).max() <= 2 ** -7, (sim, dv.max())
+        checked += len(rows)
+    assert checked > B * (T - 1) // 2
+
+
+@pytest.mark.gpu
+def test_infer_finish_inside_a_replay_of_the_reference_search():
+    """The bench's launch sequence (bl_sim_plant_root, then bl_sim_expand -> bl_sim_infer_finish per simulation) with the
+    reference's 512x4 parameters, its Dirichlet draw and its 63 x (B,T) uniforms.  The reference evaluated its leaves in f32 and
+    this path in fp16, so trees may part ways where two actions are nearly tied; what must hold:
+      * the root row within 2 f16 ulp (fp32 Linears on both sides), -inf pattern identical;
+      * every env's first simulation picks the reference's action (the root row is all it depends on, and ties at 2 ulp are
+        rarer than 1 in 64 envs) in >= 95 % of envs, and the final visit counts of the root's children agree exactly in >= 60 % of
+        the envs and in total variation <= 0.1 on average;
+      * against its OWN stored leaf evaluations the GPU search is the oracle's, bit for bit (replay_through_oracle)."""
+    import oracle_lib
+    from gpu_util import ReplayRng, bits16, to_np
+    from test_network_golden import reference_network, f16bits, FixedDraw
+    from test_gpu_parity import assert_search_equals, replay_through_oracle
+    from boardlaw_amd import networks
+    from boardlaw_amd.hex import Hex
+    from boardlaw_amd.mcts import MCTS
+    g = _gold('search_9x9_w512.npz')
+    S, B, T, width, depth, n_moves, seed = (int(x) for x in g['meta'])
+    inf = networks.Inference(reference_network(g, 'cuda'), fused=True)
+    world = Hex(board=torch.from_numpy(g['world0_board']).cuda(), seats=torch.from_numpy(g['m0_net0_seats']).cuda())
+
+    class Rng(ReplayRng):
+        def dirichlet(self, alpha, shape):
+            return torch.from_numpy(g['m0_dirichlet']).cuda()
+    m = MCTS(world, n_nodes=T, rng=Rng(g['m0_rands'], 'cuda'), obs_half=True)
+    m.initialize(inf)
+    got, want = f16bits(m.decisions.logits[:, 0]), g['m0_tree_logits'][:, 0]
+    neg = want == 0xfc00
+    assert np.array_equal(got == 0xfc00, neg) and _ulp16(got[~neg], want[~neg]).max() <= 2
+    for _ in range(T - 1):
+        m.simulate(inf)
+    # (1) the GPU search is exact given its own leaf evaluations
+    orc = oracle_lib.load()
+    mine = replay_through_oracle(orc, g['world0_board'], g['m0_net0_seats'].astype(np.int32), T, g['m0_rands'], bits16(m.decisions.logits), bits16(m.decisions.v))
+    assert_search_equals(m, mine)
+    # (2) and statistically the reference's search
+    first = to_np(m.tree.relation[:, 1]) == g['m0_relation'][:, 1]
+    assert first.mean() >= 0.95, first.mean()
+    A = S * S
+    def root_visits(children, n):
+        out = np.zeros((B, A), np.int64)
+        for b in range(B):
+            for a in range(A):
+                c = children[b, 0, a]
+                if c >= 0:
+                    out[b, a] = n[b, c]
+        return out
+    mine_v, ref_v = root_visits(to_np(m.tree.children), to_np(m.stats.n)), root_visits(g['m0_children'], g['m0_n'])
+    same = (mine_v == ref_v).all(-1)
+    tv = 0.5 * np.abs(mine_v / mine_v.sum(-1, keepdims=True) - ref_v / ref_v.sum(-1, keepdims=True)).sum(-1)
+    assert same.mean() >= 0.6 and tv.mean() <= 0.1, (same.mean(), tv.mean())

@@ -1,0 +1,137 @@
+"""The reference's RNG protocol: one `at::rand_like` (B,T) f16 per descend
+(boardlaw/mcts/cpp/cuda.cu:191), torch's Dirichlet at mcts/__init__.py:16-18, Categorical.sample at :221, all from torch's
+generator.  MoveRng serves the T-1 descend draws of a move from ONE launch (bl_rand_block) and must be STREAM-IDENTICAL: the
+same numbers as the T-1 calls, the same generator offset afterwards, eagerly and inside a captured HIP graph."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+
+
+def _offset():
+    return torch.cuda.default_generators[torch.cuda.current_device()].get_offset()
+
+
+@pytest.mark.parametrize('shape,n_calls', [((4096, 64), 63), ((1024, 256), 7), ((64, 16), 15), ((333, 64), 5), ((1, 1), 3),
+                                           ((32768, 128), 2), ((40000, 64), 3)])
+def test_rand_block_equals_stacked_rand_like(shape, n_calls):
+    """Same seed -> the block is the n_calls rand_like tensors, bit for bit, and the generator ends at the same offset.
+    (32768,128) and (40000,64) exceed 4 * torch's thread count: several Philox blocks per thread and the float4's later
+    components come into play."""
+    from boardlaw_amd.mcts import MoveRng
+    like = torch.empty(shape, dtype=torch.half, device=DEV)
+    torch.manual_seed(1234)
+    torch.rand(7, device=DEV)                               # a non-zero starting offset
+    want = torch.stack([torch.rand_like(like) for _ in range(n_calls)])
+    end = _offset()
+    torch.manual_seed(1234)
+    torch.rand(7, device=DEV)
+    rng = MoveRng()
+    rng.start(n_calls)
+    got = torch.stack([rng.rand_like(like) for _ in range(n_calls)])
+    assert torch.equal(got.view(torch.int16), want.view(torch.int16))
+    assert _offset() == end
+    assert float(got.float().max()) < 1.0 and float(got.float().min()) >= 0.0
+    # a further draw falls back to torch's own call and stays on the stream
+    nxt = rng.rand_like(like)
+    torch.manual_seed(1234)
+    torch.rand(7, device=DEV)
+    for _ in range(n_calls):
+        torch.rand_like(like)
+    assert torch.equal(nxt, torch.rand_like(like))
+
+
+def test_rand_block_with_a_private_generator():
+    from boardlaw_amd.mcts import MoveRng
+    like = torch.empty((512, 64), dtype=torch.half, device=DEV)
+    g1 = torch.Generator(device=DEV); g1.manual_seed(99)
+    want = torch.stack([torch.rand(like.shape, dtype=torch.half, device=DEV, generator=g1) for _ in range(9)])
+    g2 = torch.Generator(device=DEV); g2.manual_seed(99)
+    before = _offset()
+    rng = MoveRng(generator=g2)
+    rng.start(9)
+    got = torch.stack([rng.rand_like(like) for _ in range(9)])
+    assert torch.equal(got.view(torch.int16), want.view(torch.int16)) and g1.get_offset() == g2.get_offset()
+    assert _offset() == before, 'the default generator must not be touched'
+
+
+def test_rand_block_inside_a_captured_graph():
+    """Captured once, replayed three times: every replay continues the generator's stream exactly like a graph of rand_like calls
+    (torch refills the graph's seed/offset tensors before each replay; the kernel reads them like torch's kernels do)."""
+    from boardlaw_amd.mcts import MoveRng
+    like = torch.empty((2048, 64), dtype=torch.half, device=DEV)
+    n_calls = 11
+
+    def capture(fn):
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            fn()
+        torch.cuda.current_stream().wait_stream(side)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            out = fn()
+        return g, out
+
+    def reference():
+        a = torch._sample_dirichlet(torch.full((2048, 81), 10 / 81, device=DEV))
+        return a, torch.stack([torch.rand_like(like) for _ in range(n_calls)])
+
+    rng = MoveRng()
+
+    def mine():
+        rng.start(n_calls)
+        a = rng.dirichlet(torch.full((81,), 10 / 81, device=DEV), (2048,))
+        return a, torch.stack([rng.rand_like(like) for _ in range(n_calls)])
+
+    g_ref, out_ref = capture(reference)
+    g_mine, out_mine = capture(mine)
+    torch.manual_seed(7)
+    wants = []
+    for _ in range(3):
+        g_ref.replay()
+        wants.append([t.clone() for t in out_ref])
+    end = _offset()
+    torch.manual_seed(7)
+    for r in range(3):
+        g_mine.replay()
+        assert torch.equal(out_mine[0], wants[r][0]), r
+        assert torch.equal(out_mine[1].view(torch.int16), wants[r][1].view(torch.int16)), r
+    assert _offset() == end
+    assert not torch.equal(wants[0][1], wants[1][1])
+
+
+@pytest.mark.parametrize('graph', [False, True])
+@pytest.mark.parametrize('S,B,T,width,depth', [(9, 512, 64, 256, 2), (5, 64, 16, 32, 2)])
+def test_seeded_agent_under_move_rng_is_the_torch_rng_agent(S, B, T, width, depth, graph):
+    """MCTSAgent(rng=MoveRng()) == MCTSAgent(rng=TorchRng()) under one seed, for three consecutive self-play moves: every
+    decision output, the worlds, and the generator's offset -- i.e. a seeded run consumes the generator like the reference."""
+    from boardlaw_amd import networks
+    from boardlaw_amd.hex import Hex
+    from boardlaw_amd.mcts import MCTSAgent, MoveRng, TorchRng
+    torch.manual_seed(3)
+    worlds0 = Hex.initial(B, S)
+    net = networks.Inference(networks.FCModel(worlds0.obs_space, worlds0.action_space, width=width, depth=depth).cuda(), fused=True)
+    runs = {}
+    for name, rng in (('torch', TorchRng()), ('move', MoveRng())):
+        agent = MCTSAgent(net, n_nodes=T, graph=graph, rng=rng)
+        worlds = worlds0
+        if graph:
+            agent.play(worlds)                 # capture + warm-up consume the generator differently in the two agents: reseed after
+        torch.manual_seed(11)
+        outs = []
+        for _ in range(3):
+            d, worlds, t = agent.play(worlds)
+            outs.append((d, worlds.board.clone(), worlds.seats.clone()))
+        runs[name] = (outs, _offset())
+    (a, off_a), (b, off_b) = runs['torch'], runs['move']
+    assert off_a == off_b
+    for (da, ba, sa), (db, bb, sb) in zip(a, b):
+        for k in ('logits', 'prior', 'v', 'actions', 'n_leaves', 'n_sims'):
+            x, y = da[k], db[k]
+            if x.dtype == torch.half:
+                x, y = x.view(torch.int16), y.view(torch.int16)
+            assert torch.equal(x, y), k
+        assert torch.equal(ba, bb) and torch.equal(sa, sb)
