@@ -131,10 +131,13 @@ def dry_run(args):
     t0 = time.perf_counter()
     time.sleep(0.01 * (rank + 1))
     parallel.barrier()
-    elapsed = parallel.max_over_ranks(time.perf_counter() - t0, device='cpu')
+    own = time.perf_counter() - t0
+    elapsed = parallel.max_over_ranks(own, device='cpu')
+    per_rank, seen = parallel.gather_over_ranks(float(rank + 1), device='cpu')
     if rank == 0:
         print(json.dumps({'metric': 'mcts_sims_per_sec', 'value': 0.0, 'unit': 'sims/s', 'n_gpus': world, 'steps': args.steps,
-                          'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed, 'dry_run': True}))
+                          'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed, 'dry_run': True, 'per_rank_values': per_rank,
+                          'ranks_seen': seen}))
     if world > 1:
         torch.distributed.destroy_process_group()
 
@@ -214,6 +217,8 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     timer.on = False
+    # every rank's own rate and a count of the ranks, through the collective itself (RCCL on GPUs): the line proves N ranks ran
+    per_rank_values, ranks_seen = parallel.gather_over_ranks(args.envs * NODES * args.steps / elapsed)
     elapsed = parallel.max_over_ranks(elapsed)
 
     sims_total = world * args.envs * NODES * args.steps
@@ -222,7 +227,8 @@ def main():
     if args.timed_only:
         if rank == 0:
             print(json.dumps({'metric': 'mcts_sims_per_sec', 'value': value, 'unit': 'sims/s', 'n_gpus': world, 'steps': args.steps,
-                              'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps, 'timed_only': True}))
+                              'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps, 'timed_only': True,
+                              'per_rank_values': per_rank_values, 'ranks_seen': ranks_seen}))
         if world > 1:
             torch.distributed.destroy_process_group()
         return
@@ -319,6 +325,7 @@ def main():
             'metric': 'mcts_sims_per_sec', 'value': value, 'unit': 'sims/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps, 'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f16', 'data': 'synthetic',
+            'per_rank_values': per_rank_values, 'ranks_seen': ranks_seen,
             'config': {'workload': f'{BOARD}x{BOARD} Hex, {args.envs} envs/GPU x {NODES} sims/move, FCModel {WIDTH}x{DEPTH} fp16 autocast'
                                    + (' (BASELINE config 2)' if default_shape and args.envs == ENVS else ' (NOT the metric\'s configuration)')
                                    + '; step = one self-play move of the batch',

@@ -15,12 +15,17 @@ QRANGE_WORDS = 4096
 _vp, _i = ctypes.c_void_p, ctypes.c_int
 
 
+class Tune(ctypes.Structure):
+    """bl_tune_t: explicit tuning choices (zero = defaults); results never depend on them."""
+    _fields_ = [(k, _i) for k in ('fold_fast', 'expand_waves', 'expand_deep', 'expand_legacy', 'group', 'mlp_no_xcd')]
+
+
 class Search(ctypes.Structure):
     """bl_search_t"""
     _fields_ = [(k, _vp) for k in ('logits', 'v', 'w', 'n', 'children', 'parents', 'relation', 'rewards', 'terminal',
                                    'boards', 'seats', 'c_puct', 'qrange', 'exp_table')] + \
                [('B', _i), ('T', _i), ('boardsize', _i), ('obs_f16', _i), ('path', _vp), ('order', _vp), ('prio_thresh', _i),
-                ('cpi', _vp), ('cca', _vp), ('nk', _vp), ('fav', _vp)]
+                ('cpi', _vp), ('cca', _vp), ('nk', _vp), ('fav', _vp), ('tune', Tune), ('n_active', _vp)]
 
 
 SYMBOLS = {
@@ -30,7 +35,9 @@ SYMBOLS = {
     'bl_mcts_qrange': (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
     'bl_qrange_decode': (_i, [_vp, _vp]),
     'bl_mcts_descend': (_i, [_vp] * 10 + [_i] * 4 + [_vp, _vp, _vp]),
+    'bl_mcts_descend_tuned': (_i, [ctypes.POINTER(Tune)] + [_vp] * 10 + [_i] * 4 + [_vp, _vp, _vp]),
     'bl_mcts_root': (_i, [_vp] * 9 + [_i] * 4 + [_vp, _vp]),
+    'bl_mcts_root_tuned': (_i, [ctypes.POINTER(Tune)] + [_vp] * 9 + [_i] * 4 + [_vp, _vp]),
     'bl_mcts_backup': (_i, [_vp] * 7 + [_i] * 3 + [_vp]),
     'bl_hex_step': (_i, [_vp] * 4 + [_i, _i, _vp]),
     'bl_hex_observe': (_i, [_vp] * 3 + [_i, _i, _vp]),
@@ -55,7 +62,6 @@ SYMBOLS = {
     'bl_copy_many': (_i, [_vp, _i, _vp]),
     'bl_rand_block': (_i, [_vp, _i, ctypes.c_long, ctypes.c_long, _i, ctypes.c_ulonglong, ctypes.c_ulonglong, ctypes.c_uint, _i, _vp]),
     'bl_selftest': (_i, [_vp]),
-    'bl_fold_variant': (_i, []),
 }
 
 _lib = None
@@ -78,12 +84,42 @@ def lib():
             f = getattr(L, name)
             f.restype, f.argtypes = res, args
         _lib = L
-        if torch.cuda.is_available() and not torch.cuda.is_current_stream_capturing():
-            # verifies the one-wait-state DPP fold on this device; the ISA-padded variant stays in use otherwise
-            rc = L.bl_selftest(torch.cuda.current_stream().cuda_stream)
-            if rc < 0:
-                raise NativeError(f'libboardlaw_amd: device self-test failed ({L.bl_strerror(rc).decode()})')
     return _lib
+
+
+_fold_fast = {}
+
+
+def fold_fast(device):
+    """1 if bl_sim_expand may use its one-wait-state DPP fold on `device`: bl_selftest() reproduced every prefix total with it
+    THERE (run once per device, outside any capture), and BL_FOLD_SAFE is not set.  Inside a capture on a device that has not
+    been tested yet the ISA-padded fold is used (and nothing is cached)."""
+    device = torch.device(device)
+    index = device.index if device.index is not None else torch.cuda.current_device()
+    if index not in _fold_fast:
+        if torch.cuda.is_current_stream_capturing():
+            return 0
+        with torch.cuda.device(index):
+            rc = lib().bl_selftest(torch.cuda.current_stream().cuda_stream)
+        if rc < 0:
+            raise NativeError(f'libboardlaw_amd: device self-test failed on cuda:{index} ({lib().bl_strerror(rc).decode()})')
+        _fold_fast[index] = int(rc == 0)
+    return 0 if _env_int('BL_FOLD_SAFE') else _fold_fast[index]
+
+
+def _env_int(name, default=0):
+    try:
+        return int(os.environ.get(name, default))
+    except ValueError:
+        return default
+
+
+def tune(device=None):
+    """bl_tune_t for searches on `device`.  The BL_* environment variables are experiment switches of THIS host layer (tools/,
+    parity tests of the kernel variants); the library itself reads no environment."""
+    return Tune(fold_fast=fold_fast(device) if device is not None else 0, expand_waves=_env_int('BL_EXPAND_WAVES'),
+                expand_deep=_env_int('BL_EXPAND_DEEP'), expand_legacy=_env_int('BL_EXPAND_LEGACY'), group=_env_int('BL_FORCE_GROUP'),
+                mlp_no_xcd=int(os.environ.get('BL_MLP_XCD', '1') == '0'))
 
 
 GENLIBPATH = os.path.join(HERE, 'libbl_torchgen.so')

@@ -70,7 +70,7 @@ def evaluate(worlds, agents):
 # --------------------------------------------------------------------------------------------------------------------
 def live_indices(residual):
     """(n,n) counts -> (sum(residual), 2) rows [i, j], residual[i, j] copies of each pair, pairs in row-major order."""
-    residual = torch.as_tensor(residual).int()
+    residual = torch.as_tensor(residual).int().clamp(min=0)     # a pair with more games than asked for gets no env (neural.py:40-44)
     assert int(residual.sum()) < 100 * 1024 * 1024
     pairs = residual.nonzero(as_tuple=False)
     return pairs.repeat_interleave(residual[pairs[:, 0], pairs[:, 1]].long(), 0)
@@ -187,6 +187,124 @@ def evaluate_chunk(worldfunc, agentfunc, subgames, n_envs_per):
     while not evaluator.finished():
         results.extend(evaluator.step())
     return results
+
+
+
+
+# --------------------------------------------------------------------------------------------------------------------
+# Fan-out over GPUs (boardlaw/arena/neural.py:202-274 `evaluate_gen`, rebar/parallel.py:28-57 `CUDAPoolExecutor`): the games
+# matrix is cut into diagonal and skew blocks of agents, every block is an `evaluate_chunk` job, and a pool of worker
+# processes -- worker n pinned to GPU n % n_gpus, one process per GPU when n_workers == n_gpus -- plays them.  No collective:
+# jobs are independent, results come back through a queue.
+# --------------------------------------------------------------------------------------------------------------------
+def chunk_jobs(games, names, n_envs_per, chunks):
+    """neural.py:205-232: {(i, j): (names of the block, games played so far within it)} for every diagonal block i == j and every
+    pair of blocks i < j that still has games to play.  Within a skew block the two diagonal sub-blocks count as played."""
+    games = np.asarray(games)
+    names = list(names)
+    if isinstance(chunks, int):
+        chunks = [list(range(i, min(i + chunks, len(names)))) for i in range(0, len(names), chunks)]
+    else:
+        chunks = [[names.index(n) for n in c] for c in chunks]
+    jobs = {}
+    for i, c in enumerate(chunks):
+        sub = games[np.ix_(c, c)].copy()
+        sub[np.diag_indices_from(sub)] = n_envs_per
+        if (sub < n_envs_per).any():
+            jobs[i, i] = ([names[k] for k in c], sub)
+    for i in range(len(chunks)):
+        for j in range(i + 1, len(chunks)):
+            both = chunks[i] + chunks[j]
+            sub = games[np.ix_(both, both)].copy()
+            a = len(chunks[i])
+            sub[:a, :a] = n_envs_per
+            sub[a:, a:] = n_envs_per
+            if (sub < n_envs_per).any():
+                jobs[i, j] = ([names[k] for k in both], sub)
+    return jobs
+
+
+def _chunk_job(worldfunc, agentfunc, names, played, n_envs_per):
+    agents = {n: agentfunc(n) for n in names}
+    device = 'cuda' if torch.cuda.is_available() else 'cpu'
+    evaluator = ChunkEvaluator(worldfunc, agents, None, n_envs_per=n_envs_per, device=device)
+    evaluator.tracker = Tracker(n_envs_per, played, names=names, device=device)      # games already on record are not replayed
+    evaluator.worlds = worldfunc(evaluator.tracker.n_envs).to(device)
+    results = []
+    while not evaluator.finished():
+        results.extend(evaluator.step())
+    return [dict(r) for r in results]
+
+
+def _pool_worker(index, n_devices, inbox, outbox):
+    """One worker process: pinned to GPU index % n_devices (rebar/parallel.py:31-35 does this with CUDA_VISIBLE_DEVICES before
+    CUDA comes up; here the runtime is initialised lazily, so selecting the device is enough and the ids stay global)."""
+    if n_devices > 0:
+        torch.cuda.set_device(index % n_devices)
+    while True:
+        item = inbox.get()
+        if item is None:
+            return
+        key, fn, args = item
+        try:
+            with torch.no_grad():
+                outbox.put((key, fn(*args), None))
+        except BaseException as e:           # the parent re-raises
+            import traceback
+            outbox.put((key, None, f'{type(e).__name__}: {e}\\n{traceback.format_exc()}'))
+
+
+def run_jobs(jobs, n_workers=None, context='spawn'):
+    """jobs: {key: (picklable function, args)} -> yields (key, result) as they finish, from a pool of n_workers processes, one
+    per GPU by default (worker n on GPU n % n_gpus).  n_workers == 0: everything in this process, in order (the reference's
+    serial executor, rebar/parallel.py:15-27)."""
+    n_devices = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if n_workers is None:
+        n_workers = max(n_devices, 1)
+    if n_workers == 0:
+        for key, (fn, args) in jobs.items():
+            yield key, fn(*args)
+        return
+    import torch.multiprocessing as mp
+    ctx = mp.get_context(context)
+    inbox, outbox = ctx.Queue(), ctx.Queue()
+    procs = [ctx.Process(target=_pool_worker, args=(i, n_devices, inbox, outbox), daemon=True) for i in range(min(n_workers, max(len(jobs), 1)))]
+    for p in procs:
+        p.start()
+    try:
+        for key, (fn, args) in jobs.items():
+            inbox.put((key, fn, args))
+        for _ in procs:
+            inbox.put(None)
+        for _ in range(len(jobs)):
+            key, result, err = outbox.get()
+            if err is not None:
+                raise RuntimeError(f'arena job {key} failed in its worker:\\n{err}')
+            yield key, result
+    finally:
+        for p in procs:
+            p.join(timeout=30)
+            if p.is_alive():
+                p.terminate()
+
+
+def evaluate_gen(worldfunc, agentfunc, games, names=None, n_envs_per=512, chunks=64, n_workers=None, context='spawn'):
+    """neural.py:202-274: plays every missing game of an all-vs-all `games` matrix ((n,n) games played per ordered pair; a pandas
+    DataFrame indexed by name, or an array with `names`), block by block, on a pool of worker processes (one per GPU by default).
+    Yields (list of result records of one finished block, running totals) as blocks finish.  worldfunc(n_envs) and
+    agentfunc(name) must be picklable (module-level functions); they run in the workers."""
+    if hasattr(games, 'index'):
+        assert list(games.index) == list(games.columns)
+        names, games = list(games.index), games.values
+    jobs = {k: (_chunk_job, (worldfunc, agentfunc, block_names, played, n_envs_per)) for k, (block_names, played) in chunk_jobs(games, names, n_envs_per, chunks).items()}
+    stats = arrdict.dotdict(finished=0, total=len(jobs), moves=0., games=0., matchups=0, start=time.time())
+    for key, records in run_jobs(jobs, n_workers, context):
+        results = [arrdict.dotdict(r) for r in records]
+        stats['finished'] += 1
+        stats['end'] = time.time()
+        for r in results:
+            stats['moves'] += r.moves; stats['games'] += r.games; stats['matchups'] += 1
+        yield results, arrdict.dotdict(stats)
 
 
 from .analysis import rollout  # noqa: E402,F401  (kept here for callers that imported it from arena)

@@ -205,7 +205,12 @@ struct Search {
     const float* exp_table; int B, T, S; int obs_f16; int16_t* path; const int32_t* order; int prio_thresh;
     float* cpi; uint32_t* cca; int16_t* nk;      // compacted policy rows, see compact_store()
     int16_t* fav;                                // (B,T) most visited child of a node, a hint for bl_expand.hip's speculative batches
+    const int32_t* n_active;                     // device scalar or null: envs >= *n_active sit the simulation out
 };
+
+// number of envs that take part (bl_search_t.n_active); a scalar load
+__device__ __forceinline__ int active_envs(const Search& s) { return s.n_active ? __builtin_amdgcn_readfirstlane(*s.n_active) : s.B; }
+
 
 // ------------------------------------------------------------------------------------------------------------------
 // Compacted policy rows.  A descent level needs, per action with pi = expf(logit) != 0, {pi, the action, its child}.

@@ -44,10 +44,12 @@ __device__ __forceinline__ void fold7(float& x, const float t) {
     if constexpr (FAST) asm volatile("s_nop 0\n\t" BLX_STEP7("s_nop 0\n\t") : "+v"(x) : "v"(t));
     else asm volatile("s_nop 1\n\t" BLX_STEP7("s_nop 1\n\t") : "+v"(x) : "v"(t));
 }
+// Every asm block starts with its own wait state(s): the compiler may place a VALU write of x (a copy, a select) between two
+// blocks, and the first DPP read of a block must not rely on the previous block's trailing nop.
 template <bool FAST>
 __device__ __forceinline__ void fold8(float& x, const float t) {
-    if constexpr (FAST) asm volatile(BLX_STEP8("s_nop 0\n\t") : "+v"(x) : "v"(t));
-    else asm volatile(BLX_STEP8("s_nop 1\n\t") : "+v"(x) : "v"(t));
+    if constexpr (FAST) asm volatile("s_nop 0\n\t" BLX_STEP8("s_nop 0\n\t") : "+v"(x) : "v"(t));
+    else asm volatile("s_nop 1\n\t" BLX_STEP8("s_nop 1\n\t") : "+v"(x) : "v"(t));
 }
 
 // One block of m <= 32 elements whose lanes 0 and 32 already hold their final values.
@@ -114,6 +116,7 @@ __global__ void __launch_bounds__(BL_WAVE * NW, (RMAX <= 3 ? 8 : 4)) sim_expand2
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int slot = blockIdx.x;
     const int b = s.order ? s.order[slot] : slot;
+    if (b >= active_envs(s)) return;                 // the whole workgroup: envs that sit this search out (bl_search_t.n_active)
     const long envbase = (long)b * T;
     const bool lowhalf = lane < 32;
     const int el = lane & 31;
@@ -489,6 +492,7 @@ __global__ void __launch_bounds__(BL_WAVE) sim_expand3_kernel(Search s, int sim,
     const int S = s.S, A = S * S, T = s.T;
     const int lane = threadIdx.x & 63;
     const int b = s.order ? s.order[blockIdx.x] : blockIdx.x;
+    if (b >= active_envs(s)) return;
     const long envbase = (long)b * T;
     const bool hiNode = lane >= 32;                 // which of the batch's two nodes this lane works for
     const bool isS = !((lane >> 4) & 1);            // rows 0, 2: S chain (and prob); rows 1, 3: g chain
@@ -812,7 +816,8 @@ int bl_expand2_launch(const Search& ss, int sim, const void* rands, int16_t* lea
     const dim3 grid(ss.B), block(64 * waves);
 #define BLX_LAUNCH(R_, K_, F_, C_, W_) hipLaunchKernelGGL((sim_expand2_kernel<R_, K_, F_, C_, W_>), grid, block, lds, stream, ss, sim, \
                                                           (const uint16_t*)rands, leaves, obs, valid, leaf_seats, counters, deep_thresh)
-#define BLX_MODE(R_, K_, W_) { if (counters) BLX_LAUNCH(R_, K_, true, true, W_); else if (fast) BLX_LAUNCH(R_, K_, true, false, W_); else BLX_LAUNCH(R_, K_, false, false, W_); }
+#define BLX_MODE(R_, K_, W_) { if (counters) { if (fast) BLX_LAUNCH(R_, K_, true, true, W_); else BLX_LAUNCH(R_, K_, false, true, W_); } \
+                               else if (fast) BLX_LAUNCH(R_, K_, true, false, W_); else BLX_LAUNCH(R_, K_, false, false, W_); }
 #define BLX_KT(R_, W_) { if (kt == 1) BLX_MODE(R_, 1, W_) else BLX_MODE(R_, 4, W_) }
 #define BLX_W(R_) { if (waves == 4) BLX_KT(R_, 4) else if (waves == 2) BLX_KT(R_, 2) else BLX_KT(R_, 1) }
     switch (rmax) {

@@ -656,10 +656,11 @@ __global__ void __launch_bounds__(BL_WAVE) sim_expand_kernel(Search s, int sim, 
     const int S = s.S, A = S * S, T = s.T;
     const int grp = threadIdx.x / G, gl = threadIdx.x % G;
     const int slot = blockIdx.x * (BL_WAVE / G) + grp;
-    const bool act = slot < s.B;
+    const bool inb = slot < s.B;
     // launch slot -> env: with an `order` the host decides which envs are dispatched first (oldest wave on a SIMD wins
     // the issue arbitration); results do not depend on it
-    const int b = (s.order && act) ? s.order[slot] : slot;
+    const int b = (s.order && inb) ? s.order[slot] : slot;
+    const bool act = inb && b < active_envs(s);
     const GroupLds L(smem + (size_t)grp * lds_bytes(A, true), A);
     uint8_t* cells = L.cells;
     if (s.prio_thresh > 0 && s.path && act && s.path[(long)b * (T + 2)] >= s.prio_thresh) __builtin_amdgcn_s_setprio(3);
@@ -741,7 +742,7 @@ __global__ void __launch_bounds__(BL_WAVE) sim_backup_kernel(Search s, int sim, 
     const int S = s.S, A = S * S, T = s.T;
     const int grp = threadIdx.x / G, gl = threadIdx.x % G;
     const int b = blockIdx.x * (BL_WAVE / G) + grp;
-    const bool act = b < s.B;
+    const bool act = b < active_envs(s);
     const long envbase = (long)b * T;
     uint32_t nmin = 0, vmax = 0;
     if (act) {
@@ -784,6 +785,7 @@ __global__ void __launch_bounds__(BL_WAVE) sim_finish_kernel(Search s, int sim, 
                                                             const int32_t* leaf_seats, int W, int iters) {
     const int S = s.S, A = S * S, T = s.T;
     const int b = blockIdx.x, lane = threadIdx.x;
+    if (b >= active_envs(s)) return;
     const long envbase = (long)b * T;
     const int leaf = leaves[b];
     uint16_t lb[16];
@@ -877,6 +879,7 @@ __global__ void __launch_bounds__(BL_WAVE) sim_finish_kernel(Search s, int sim, 
 // when leaves is null (a planted root).  One wave per env.
 __global__ void __launch_bounds__(BL_WAVE) compact_rows_kernel(Search s, const int16_t* leaves) {
     const int A = s.S * s.S, b = blockIdx.x, lane = threadIdx.x;
+    if (b >= active_envs(s)) return;
     const long node = (long)b * s.T + (leaves ? (int)leaves[b] : 0);
     int count = 0;
     for (int a0 = 0; a0 < A; a0 += BL_WAVE) {
@@ -1136,15 +1139,9 @@ __global__ void __launch_bounds__(256) zero_words_kernel(uint32_t* p, int n) {
 // =====================================================================================================================
 using namespace bl;
 
-// Tuning knob for experiments (read once): BL_FORCE_GROUP=8|16|32|64 overrides the heuristic below.
-static int forced_group() {
-    static int g = -1;
-    if (g < 0) { const char* e = getenv("BL_FORCE_GROUP"); g = e ? atoi(e) : 0; }
-    return g;
-}
-
-static int pick_group(int B, int A) {
-    const int f = forced_group();
+// Lanes per env in the general kernels.  `forced` (bl_tune_t.group: 8|16|32|64, 0 = none) overrides the heuristic below.
+static int pick_group(int B, int A, int forced = 0) {
+    const int f = forced;
     if ((f == 8 || f == 16 || f == 32 || f == 64) && (A + f - 1) / f <= 16) return f;
     // One wave per env whenever the action count allows (A <= 64 x 16): that is the DPP path (no LDS, no barriers,
     // serial folds across lanes).  Measured on MI355X at 9x9 it beats the narrower LDS-fold groups at every batch size
@@ -1183,7 +1180,7 @@ int bl_fold_selftest(int use_fast, hipStream_t stream);
 
 extern "C" {
 
-int bl_abi_version(void) { return 1; }
+int bl_abi_version(void) { return 2; }
 
 const char* bl_strerror(int code) {
     switch (code) {
@@ -1241,12 +1238,20 @@ int bl_mcts_descend(const void* logits, const void* w, const int16_t* n, const v
                     const uint8_t* terminal, const int16_t* children, const void* rands, const uint32_t* qr,
                     const float* exp_table, int B, int T, int A, int S, int16_t* parents, int16_t* actions,
                     bl_stream_t stream) {
+    return bl_mcts_descend_tuned(nullptr, logits, w, n, c_puct, seats, terminal, children, rands, qr, exp_table, B, T, A, S, parents,
+                                 actions, stream);
+}
+
+int bl_mcts_descend_tuned(const bl_tune_t* tune, const void* logits, const void* w, const int16_t* n, const void* c_puct,
+                          const int16_t* seats, const uint8_t* terminal, const int16_t* children, const void* rands,
+                          const uint32_t* qr, const float* exp_table, int B, int T, int A, int S, int16_t* parents,
+                          int16_t* actions, bl_stream_t stream) {
     int rc = tree_check(logits, w, n, c_puct, seats, terminal, children, qr, exp_table, B, T, A, S);
     if (rc) return rc;
     if (!rands || !parents || !actions) return BL_EINVAL;
     Tree m{(const uint16_t*)logits, (const uint16_t*)w, n, (const uint16_t*)c_puct, seats, terminal, children, qr,
            exp_table, B, T, A, S, 0};
-    const int G = pick_group(B, A), K = pick_k(A, G);
+    const int G = pick_group(B, A, tune ? tune->group : 0), K = pick_k(A, G);
     const int per = lds_bytes(A, false);
     const int blocks = (B + 64 / G - 1) / (64 / G);
 #define CALL(g, k) hipLaunchKernelGGL((descend_kernel<g, k, false>), dim3(blocks), dim3(64), (size_t)per * (64 / g), \
@@ -1259,12 +1264,18 @@ int bl_mcts_descend(const void* logits, const void* w, const int16_t* n, const v
 int bl_mcts_root(const void* logits, const void* w, const int16_t* n, const void* c_puct, const int16_t* seats,
                  const uint8_t* terminal, const int16_t* children, const uint32_t* qr, const float* exp_table,
                  int B, int T, int A, int S, void* probs, bl_stream_t stream) {
+    return bl_mcts_root_tuned(nullptr, logits, w, n, c_puct, seats, terminal, children, qr, exp_table, B, T, A, S, probs, stream);
+}
+
+int bl_mcts_root_tuned(const bl_tune_t* tune, const void* logits, const void* w, const int16_t* n, const void* c_puct,
+                       const int16_t* seats, const uint8_t* terminal, const int16_t* children, const uint32_t* qr,
+                       const float* exp_table, int B, int T, int A, int S, void* probs, bl_stream_t stream) {
     int rc = tree_check(logits, w, n, c_puct, seats, terminal, children, qr, exp_table, B, T, A, S);
     if (rc) return rc;
     if (!probs) return BL_EINVAL;
     Tree m{(const uint16_t*)logits, (const uint16_t*)w, n, (const uint16_t*)c_puct, seats, terminal, children, qr,
            exp_table, B, T, A, S, 0};
-    const int G = pick_group(B, A), K = pick_k(A, G);
+    const int G = pick_group(B, A, tune ? tune->group : 0), K = pick_k(A, G);
     const int per = lds_bytes(A, false);
     const int blocks = (B + 64 / G - 1) / (64 / G);
 #define CALL(g, k) hipLaunchKernelGGL((root_kernel<g, k>), dim3(blocks), dim3(64), (size_t)per * (64 / g), \
@@ -1341,12 +1352,8 @@ static Search to_search(const bl_search_t* s) {
     return Search{(uint16_t*)s->logits, (uint16_t*)s->v, (uint16_t*)s->w, s->n, s->children, s->parents, s->relation,
                   (uint16_t*)s->rewards, s->terminal, s->boards, s->seats, (const uint16_t*)s->c_puct, s->qrange,
                   s->exp_table, s->B, s->T, s->boardsize, s->obs_f16, s->path, s->order, s->prio_thresh,
-                  s->cpi, s->cca, s->nk, s->fav};
+                  s->cpi, s->cca, s->nk, s->fav, s->n_active};
 }
-
-// 1 once bl_selftest() has verified the one-wait-state fold on this device; BL_FOLD_SAFE=1 keeps the padded variant.
-static int g_fold_fast = 0;
-static int env_flag(const char* name) { const char* e = getenv(name); return e && atoi(e) != 0; }
 
 static int sim_expand_impl(const bl_search_t* s, int sim, const void* rands, int16_t* leaves, void* obs, uint8_t* valid,
                            int32_t* leaf_seats, unsigned long long* counters, bl_stream_t stream) {
@@ -1354,16 +1361,15 @@ static int sim_expand_impl(const bl_search_t* s, int sim, const void* rands, int
     if (rc) return rc;
     if (!rands || !leaves || !obs || !valid || !leaf_seats || sim < 1 || sim >= s->T) return BL_EINVAL;
     const int A = s->boardsize * s->boardsize;
-    static const int legacy = env_flag("BL_EXPAND_LEGACY");
-    if (!legacy && !forced_group() && s->cpi && s->cca && s->nk) {
+    const bl_tune_t& tune = s->tune;
+    if (!tune.expand_legacy && !tune.group && s->cpi && s->cca && s->nk) {
         // compacted rows + node statistics in registers + one DPP chain per level (bl_expand.hip); shapes outside its
         // template set (A > 384 or T > 256) fall through to the general kernel
-        static const int waves = getenv("BL_EXPAND_WAVES") ? atoi(getenv("BL_EXPAND_WAVES")) : 2;
-        static const int deep = getenv("BL_EXPAND_DEEP") ? atoi(getenv("BL_EXPAND_DEEP")) : 0;
-        rc = bl_expand2_launch(to_search(s), sim, rands, leaves, obs, valid, leaf_seats, counters, g_fold_fast, waves, deep, (hipStream_t)stream);
+        rc = bl_expand2_launch(to_search(s), sim, rands, leaves, obs, valid, leaf_seats, counters, tune.fold_fast != 0,
+                               tune.expand_waves ? tune.expand_waves : 2, tune.expand_deep, (hipStream_t)stream);
         if (rc != BL_ETOOBIG) return rc;
     }
-    const int G = pick_group(s->B, A), K = pick_k(A, G);
+    const int G = pick_group(s->B, A, tune.group), K = pick_k(A, G);
     const int per = lds_bytes(A, true);
     const int blocks = (s->B + 64 / G - 1) / (64 / G);
     Search ss = to_search(s);
@@ -1417,11 +1423,8 @@ int bl_selftest(bl_stream_t stream) {
     if (wrong_safe != 0) return wrong_safe < 0 ? wrong_safe : BL_ELAUNCH;      // the ISA-compliant fold must be exact
     const int wrong_fast = bl_fold_selftest(1, (hipStream_t)stream);
     if (wrong_fast < 0) return wrong_fast;
-    g_fold_fast = (wrong_fast == 0) && !env_flag("BL_FOLD_SAFE");
     return wrong_fast;
 }
-
-int bl_fold_variant(void) { return g_fold_fast; }
 
 int bl_sim_finish(const bl_search_t* s, int sim, const int16_t* leaves, const void* policy_raw, const void* value_raw,
                   const uint8_t* valid, const int32_t* leaf_seats, bl_stream_t stream) {
@@ -1476,7 +1479,7 @@ int bl_sim_root(const bl_search_t* s, int sim, void* probs, const void* log_tabl
     const int A = s->boardsize * s->boardsize;
     Tree m{(const uint16_t*)s->logits, (const uint16_t*)s->w, s->n, (const uint16_t*)s->c_puct, s->seats, s->terminal,
            s->children, s->qrange + (long)BL_QWORDS * sim, s->exp_table, s->B, s->T, A, 2, 1};
-    const int G = pick_group(s->B, A), K = pick_k(A, G);
+    const int G = pick_group(s->B, A, s->tune.group), K = pick_k(A, G);
     const int per = lds_bytes(A, false);
     const int blocks = (s->B + 64 / G - 1) / (64 / G);
 #define CALL(g, k) hipLaunchKernelGGL((root_kernel<g, k>), dim3(blocks), dim3(64), (size_t)per * (64 / g), \

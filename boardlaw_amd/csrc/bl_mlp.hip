@@ -12,6 +12,7 @@
 #include <stdlib.h>
 #include <type_traits>
 #include "../../include/boardlaw_amd.h"
+#include "bl_host.h"
 
 namespace blmlp {
 
@@ -42,6 +43,7 @@ struct Params {
     uint16_t* value;          // (M)
     int M, K0, K0pad, W, D, NH, NHpad;
     int xcd_rows;             // 1: tile i takes rows 256*(i/8) + 8*r + i%8 (rows whose index is i mod 8), else rows 32*i + r
+    const int32_t* n_active;  // device scalar or null: rows >= *n_active are treated like rows >= M (bl_search_t.n_active)
 };
 
 // What bl_sim_finish does for a leaf (heads, store, backup, next q range), as this kernel's epilogue: bl_sim_infer_finish.
@@ -225,6 +227,10 @@ __global__ void __launch_bounds__(WAVES * 64) mlp_kernel(Params p, FinArgs f) {
     // only: any mapping gives the same results.
     const int tile_j = blockIdx.x >> 3, tile_x = blockIdx.x & 7;
     auto grow = [&](int r) { return p.xcd_rows ? 256 * tile_j + 8 * r + tile_x : (int)blockIdx.x * 32 + r; };
+    // rows that exist: M, or fewer when the search runs with only its first *n_active envs (bl_search_t.n_active)
+    int Mrows = p.M;
+    if (p.n_active) { const int na = __builtin_amdgcn_readfirstlane(*p.n_active); Mrows = na < Mrows ? na : Mrows; }
+    if (grow(0) >= Mrows) return;                   // nothing in this tile (its smallest row index is row 0's)
     constexpr int NTHREADS = WAVES * 64;
     const int brow = lane & 31, hf = lane >> 5;     // this lane's batch row within the tile, and its feature half
 
@@ -263,7 +269,7 @@ __global__ void __launch_bounds__(WAVES * 64) mlp_kernel(Params p, FinArgs f) {
 #pragma unroll
                 for (int k = 0; k < WMAX; k++) {
                     const int w = c + 32 * k;
-                    st[i][k] = (w < wvalid && grow(r) < p.M) ? src[(long)grow(r) * wvalid + w] : 0u;
+                    st[i][k] = (w < wvalid && grow(r) < Mrows) ? src[(long)grow(r) * wvalid + w] : 0u;
                 }
             }
             CLK(50)
@@ -279,7 +285,7 @@ __global__ void __launch_bounds__(WAVES * 64) mlp_kernel(Params p, FinArgs f) {
             gemm_prefetch<NT, RD>(rg, p.w0, p.K0pad, wave * PASSES * NT, NT);
             for (int r = r_first; r < 32; r += NTHREADS / 32)
                 for (int w = c; w < wpr; w += 32)
-                    dst[r * (ld >> 1) + w] = (w < wvalid && grow(r) < p.M) ? src[(long)grow(r) * wvalid + w] : 0u;
+                    dst[r * (ld >> 1) + w] = (w < wvalid && grow(r) < Mrows) ? src[(long)grow(r) * wvalid + w] : 0u;
         }
     }
     CLK(52)
@@ -291,10 +297,10 @@ __global__ void __launch_bounds__(WAVES * 64) mlp_kernel(Params p, FinArgs f) {
 #pragma unroll
         for (int e = 0; e < EPW; e++) {
             const int b = grow(EPW * wave + e);
-            fb[e] = b < p.M ? b : -1;
+            fb[e] = b < Mrows ? b : -1;
             // `zero` is a VGPR the compiler cannot see through: with a provably uniform address it would move each loaded value
             // to an SGPR at once, and the s_waitcnt for that also waits for the cold weight fragments requested before
-            const long bb = (b < p.M ? b : 0) + zero;
+            const long bb = (b < Mrows ? b : 0) + zero;
             fleaf[e] = f.leaves[bb]; fmover[e] = f.leaf_seats[bb];
             const int16_t* path = f.path + bb * (f.T + 2);
             flen[e] = path[0];
@@ -482,11 +488,11 @@ __global__ void __launch_bounds__(WAVES * 64) mlp_kernel(Params p, FinArgs f) {
     if constexpr (!FINISH) {
         // coalesced stores: a wave writes one row's NH-1 policy outputs as consecutive halves
         for (int r = wave; r < 32; r += WAVES) {
-            if (grow(r) < p.M) {
+            if (grow(r) < Mrows) {
                 for (int fi = lane; fi < p.NH - 1; fi += 64) p.policy[(long)grow(r) * (p.NH - 1) + fi] = Out[r * p.NHpad + fi];
             }
         }
-        if (tid < 32 && grow(tid) < p.M) p.value[grow(tid)] = Out[tid * p.NHpad + p.NH - 1];
+        if (tid < 32 && grow(tid) < Mrows) p.value[grow(tid)] = Out[tid * p.NHpad + p.NH - 1];
     } else {
         // ---- bl_sim_finish's work for this wave's four envs, operation for operation as in bl_kernels.hip:
         // sim_finish_kernel (heads with torch's order; backup cuda.cu:205-236; transition_q's range), but PHASE by phase
@@ -815,11 +821,8 @@ static int mlp_launch(const blmlp::Params& p, const blmlp::FinArgs* fin, bl_stre
     // above the 64 KiB default the limit has to be raised per kernel (gfx950 has 160 KiB per CU)
 #define BL_MLP_LAUNCH1(NT, PASSES, WAVES, FIN, RD)                                                                         \
     {                                                                                                                  \
-        static size_t raised = 65536;                                                                                  \
-        if (lds > raised) {                                                                                            \
-            if (hipFuncSetAttribute((const void*)mlp_kernel<NT, PASSES, WAVES, FIN, RD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return BL_ELAUNCH; \
-            raised = lds;                                                                                              \
-        }                                                                                                              \
+        static size_t raised[64];                                                                                      \
+        if (!bl_raise_lds_limit((const void*)mlp_kernel<NT, PASSES, WAVES, FIN, RD>, lds, raised)) return BL_ELAUNCH;  \
         hipLaunchKernelGGL((mlp_kernel<NT, PASSES, WAVES, FIN, RD>), grid, dim3(WAVES * 64), lds, hs, p, f);               \
     }
 #define BL_MLP_LAUNCH(NT, PASSES, WAVES, RD) { if (fin) BL_MLP_LAUNCH1(NT, PASSES, WAVES, true, RD) else BL_MLP_LAUNCH1(NT, PASSES, WAVES, false, RD) }
@@ -852,7 +855,7 @@ extern "C" int bl_mlp_forward_f16(const void* obs, int M, int K0, const void* w0
     if (!policy_out || !value_out) return BL_EINVAL;
     if (int rc = mlp_check(obs, M, K0, w0, b0, wb, bb, alphas, wh, bh, W, D, K0pad, NH, NHpad)) return rc;
     Params p{(const uint16_t*)obs, (const uint16_t*)w0, (const uint16_t*)b0, (const uint16_t*)wb, (const uint16_t*)bb, alphas,
-             (const uint16_t*)wh, (const uint16_t*)bh, (uint16_t*)policy_out, (uint16_t*)value_out, M, K0, K0pad, W, D, NH, NHpad, 0};
+             (const uint16_t*)wh, (const uint16_t*)bh, (uint16_t*)policy_out, (uint16_t*)value_out, M, K0, K0pad, W, D, NH, NHpad, 0, nullptr};
     return mlp_launch(p, nullptr, stream);
 }
 
@@ -872,11 +875,8 @@ extern "C" int bl_mlp_layers_f16(const void* obs, int M, int K0, const void* w0,
         const size_t l = (size_t)32 * (Kpad + 8) * 2;
 #define BL_LAYER_LAUNCH(RD, KBC)                                                                                                  \
         {                                                                                                                         \
-            static size_t raised = 65536;                                                                                         \
-            if (l > raised) {                                                                                                     \
-                if (hipFuncSetAttribute((const void*)layer_kernel<RD, KBC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l) != hipSuccess) { rc = BL_ELAUNCH; return; } \
-                raised = l;                                                                                                       \
-            }                                                                                                                     \
+            static size_t raised[64];                                                                                             \
+            if (!bl_raise_lds_limit((const void*)layer_kernel<RD, KBC>, l, raised)) { rc = BL_ELAUNCH; return; }                   \
             hipLaunchKernelGGL((layer_kernel<RD, KBC>), grid, dim3(256), l, hs, a);                                               \
         }
         switch (Kpad) {
@@ -914,9 +914,9 @@ extern "C" int bl_sim_infer_finish(const bl_search_t* s, int sim, const int16_t*
     const int A = s->boardsize * s->boardsize, M = s->B, K0 = 2 * A, NH = A + 1;
     if (s->T > 64 || A > 128 || W < 256) return BL_ETOOBIG;     // the epilogue keeps a whole env in one wave's registers
     if (int rc = mlp_check(obs, M, K0, w0, b0, wb, bb, alphas, wh, bh, W, D, K0pad, NH, NHpad)) return rc;
-    static const int xcd_rows = getenv("BL_MLP_XCD") ? atoi(getenv("BL_MLP_XCD")) != 0 : 1;     // tiles of same-XCD envs (see mlp_kernel)
+    const int xcd_rows = s->tune.mlp_no_xcd ? 0 : 1;     // tiles of same-XCD envs (see mlp_kernel)
     Params p{(const uint16_t*)obs, (const uint16_t*)w0, (const uint16_t*)b0, (const uint16_t*)wb, (const uint16_t*)bb, alphas,
-             (const uint16_t*)wh, (const uint16_t*)bh, nullptr, nullptr, M, K0, K0pad, W, D, NH, NHpad, xcd_rows};
+             (const uint16_t*)wh, (const uint16_t*)bh, nullptr, nullptr, M, K0, K0pad, W, D, NH, NHpad, xcd_rows, s->n_active};
     int np2 = 1; while (np2 < A) np2 *= 2;
     const int Wsm = np2 < 64 ? np2 : 64;
     FinArgs f{(uint16_t*)s->logits, (uint16_t*)s->v, (uint16_t*)s->w, s->n, (const uint16_t*)s->rewards, s->terminal, s->path,

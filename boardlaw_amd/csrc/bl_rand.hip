@@ -34,6 +34,8 @@ __device__ __forceinline__ uint16_t uniform_f16(unsigned int u) {
     return h == 0x3c00u ? (uint16_t)0 : h;
 }
 
+// grid: x over a call's threads (idx), y over (call, loop) -- no integer division anywhere; the launch is bound by the Philox
+// rounds' 32-bit multiplies (quarter rate), 40 per element at torch's one-element-per-thread geometry
 __global__ void __launch_bounds__(256) rand_block_kernel(uint16_t* out, int n_calls, long numel, long threads, int loops,
                                                          unsigned long long seed_or_ptr, unsigned long long offset_or_ptr,
                                                          unsigned int intragraph, int captured) {
@@ -43,15 +45,15 @@ __global__ void __launch_bounds__(256) rand_block_kernel(uint16_t* out, int n_ca
         seed = (unsigned long long)*(const long long*)seed_or_ptr;
         offset = (unsigned long long)*(const long long*)offset_or_ptr + intragraph;
     }
-    const long per_call = threads * loops;
-    const long total = per_call * n_calls;
-    for (long g = (long)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (long)gridDim.x * blockDim.x) {
-        const long c = g / per_call, rem = g - c * per_call;
-        const long l = rem / threads, idx = rem - l * threads;
-        const unsigned long long ctr = offset / 4 + (unsigned long long)c * loops + l;
-        const uint4 r = philox4x32_10(uint4{(unsigned)ctr, (unsigned)(ctr >> 32), (unsigned)idx, (unsigned)((unsigned long long)idx >> 32)},
-                                      uint2{(unsigned)seed, (unsigned)(seed >> 32)});
-        uint16_t* dst = out + c * numel;
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= threads) return;
+    const uint2 key{(unsigned)seed, (unsigned)(seed >> 32)};
+    for (int cl = blockIdx.y; cl < n_calls * loops; cl += gridDim.y) {          // cl = c * loops + l
+        int c = cl, l = 0;
+        if (loops > 1) { c = cl / loops; l = cl - c * loops; }
+        const unsigned long long ctr = offset / 4 + (unsigned long long)cl;
+        const uint4 r = philox4x32_10(uint4{(unsigned)ctr, (unsigned)(ctr >> 32), (unsigned)idx, (unsigned)((unsigned long long)idx >> 32)}, key);
+        uint16_t* dst = out + (long)c * numel;
         const long li = idx + threads * 4 * l;
         if (li < numel) dst[li] = uniform_f16(r.x);
         if (li + threads < numel) dst[li + threads] = uniform_f16(r.y);
@@ -67,10 +69,9 @@ extern "C" int bl_rand_block(void* out, int n_calls, long numel, long threads, i
     if (!out || n_calls <= 0 || numel <= 0 || threads <= 0 || threads % 256 != 0 || loops <= 0) return BL_EINVAL;
     if ((long)loops * threads * 4 < numel || (long)(loops - 1) * threads * 4 >= numel) return BL_EINVAL;     // loops = (numel-1)/(4*threads)+1
     if (captured && (!seed_or_ptr || !offset_or_ptr)) return BL_EINVAL;
-    const long total = threads * loops * (long)n_calls;
-    long blocks = (total + 255) / 256;
-    if (blocks > 65536) blocks = 65536;
-    hipLaunchKernelGGL(bl::rand_block_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (uint16_t*)out, n_calls, numel,
-                       threads, loops, seed_or_ptr, offset_or_ptr, offset_intragraph, captured);
+    long gy = (long)n_calls * loops;
+    if (gy > 65535) gy = 65535;
+    hipLaunchKernelGGL(bl::rand_block_kernel, dim3((unsigned)(threads / 256), (unsigned)gy), dim3(256), 0, (hipStream_t)stream, (uint16_t*)out,
+                       n_calls, numel, threads, loops, seed_or_ptr, offset_or_ptr, offset_intragraph, captured);
     return hipGetLastError() == hipSuccess ? BL_OK : BL_ELAUNCH;
 }

@@ -17,6 +17,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "../../include/boardlaw_amd.h"
+#include "bl_host.h"
 
 namespace blroot {
 
@@ -163,11 +164,8 @@ extern "C" int bl_root_mlp_f32(const float* obs, int M, int K0, const float* w0,
     // above the 64 KiB default the dynamic LDS limit has to be raised per kernel (gfx950 has 160 KiB per CU)
 #define BL_ROOT_LAUNCH(NT)                                                                                              \
     {                                                                                                                   \
-        static size_t raised = 65536;                                                                                   \
-        if (lds > raised) {                                                                                             \
-            if (hipFuncSetAttribute((const void*)root_mlp_kernel<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return BL_ELAUNCH; \
-            raised = lds;                                                                                               \
-        }                                                                                                               \
+        static size_t raised[64];                                                                                       \
+        if (!bl_raise_lds_limit((const void*)root_mlp_kernel<NT>, lds, raised)) return BL_ELAUNCH;                     \
         hipLaunchKernelGGL((root_mlp_kernel<NT>), grid, dim3(512), lds, hs, p);                                         \
     }
     switch (W / 128) {

@@ -97,12 +97,16 @@ class MoveRng(TorchRng):
         return torch._sample_dirichlet(alpha.expand(*shape, alpha.shape[-1]), self.generator)
 
     def categorical(self, logits):
-        if self.generator is None:
-            return super().categorical(logits)
-        # Categorical(logits=...).sample() with a private generator: what torch.distributions does (normalise, softmax,
-        # multinomial of one draw with replacement), the generator passed through
+        """torch.distributions.Categorical(logits=logits).sample() with this rng's generator, minus argument checking: the
+        normalisation and softmax of Categorical.__init__/probs, then what torch.multinomial does for ONE draw with replacement
+        once it has validated its input (aten/src/ATen/native/Distributions.cpp: q = exponential_(1) noise, argmax(probs / q)).
+        Same kernels on the same values and the same use of the generator -- the same actions as TorchRng.categorical -- without
+        multinomial's eight validation launches (two of them device-side asserts)."""
         probs = torch.softmax(logits - logits.logsumexp(-1, keepdim=True), -1)
-        return torch.multinomial(probs.reshape(-1, probs.shape[-1]), 1, True, generator=self.generator).reshape(probs.shape[:-1])
+        flat = probs.reshape(-1, probs.shape[-1])
+        q = torch.empty_like(flat).exponential_(1, generator=self.generator)
+        torch.div(flat, q, out=q)
+        return q.argmax(-1).reshape(probs.shape[:-1])
 
 
 class FastRng(MoveRng):
@@ -154,8 +158,11 @@ class LeafWorlds:
 class MCTS:
 
     def __init__(self, world, n_nodes=64, c_puct=1 / 16, noise_eps=.25, alpha_scale=10, fused=None, rng=None,
-                 count=False, obs_half=False, qrange_sync=None, fuse_finish=True):
-        """c_puct high: concentrates on prior; c_puct low: concentrates on value (mcts/__init__.py:29-33)."""
+                 count=False, obs_half=False, qrange_sync=None, fuse_finish=True, n_active=None):
+        """c_puct high: concentrates on prior; c_puct low: concentrates on value (mcts/__init__.py:29-33).
+        n_active (fused path): a one-element int32 DEVICE tensor -- only the first n_active[0] envs of `world` are searched, the
+        rest sit the simulations out and add nothing to the q-range (bl_search_t.n_active): what lets one captured move of B
+        envs serve masked calls of any size <= B."""
         from .. import hex as hexmod
         self.device = world.device
         self.n_envs = world.n_envs
@@ -211,7 +218,11 @@ class MCTS:
                 seats=self.worlds.seats.data_ptr(), c_puct=self.c_puct.data_ptr(), qrange=self._qrange.data_ptr(),
                 exp_table=self._exp.data_ptr(), B=B, T=T, boardsize=bs, obs_f16=int(obs_half),
                 path=self._path.data_ptr(), cpi=self._cpi.data_ptr(), cca=self._cca.data_ptr(), nk=self._nk.data_ptr(),
-                fav=self._fav.data_ptr())
+                fav=self._fav.data_ptr(), tune=_native.tune(dev))
+            if n_active is not None:
+                assert n_active.dtype == torch.int32 and n_active.numel() == 1 and n_active.device == world.board.device
+                self._n_active = n_active                      # kept alive: the kernels read it through the pointer
+                self._search.n_active = n_active.data_ptr()
             with torch.cuda.device(dev):
                 _native.check(_native.lib().bl_sim_init(ctypes.byref(self._search), world.board.contiguous().data_ptr(),
                                                         world.seats.int().contiguous().data_ptr(), _native.stream(dev)))
@@ -445,11 +456,25 @@ class MCTSAgent:
     REFERENCE_KWARGS = ('n_nodes', 'c_puct', 'noise_eps', 'alpha_scale')
     GRAPH_CACHE_BYTES = 8 << 30     # captured moves kept alive (each owns a whole tree): least recently used go first
 
-    def __init__(self, network, graph=False, **kwargs):
+    MIN_CAPACITY = 64
+
+    def __init__(self, network, graph=False, pad=True, **kwargs):
+        """pad (with graph=True): a call of n envs replays a move captured for the next power of two >= n with the extra rows
+        switched off on the device (MCTS n_active), so the arena's masked calls -- a different n every round
+        (arena/common.py:88-93) -- share a handful of captures instead of capturing every round."""
         self.network = network
         self.kwargs = kwargs
         self.graph = graph
+        self.pad = pad
         self._graphs = {}           # insertion-ordered: oldest use first
+
+    def _capacity(self, n):
+        if not self.pad:
+            return n
+        cap = self.MIN_CAPACITY
+        while cap < n:
+            cap *= 2
+        return cap
 
     def _kwargs_key(self):
         # the reference mutates agent.kwargs in place (arena: kwargs['n_nodes'] = ...): a captured move belongs to the
@@ -490,8 +515,9 @@ class MCTSAgent:
     def __call__(self, world, value=True, eval=False, **kwargs):
         if not self.graph or kwargs or world.device.type != 'cuda':
             return self._move(world, eval, kwargs)
-        key = (type(world), world.n_envs, world.boardsize, bool(eval), world.device)
-        return self._graphed(key, lambda: _GraphedMove(self, world, eval))(world)
+        cap = self._capacity(world.n_envs)
+        key = (type(world), cap, world.boardsize, bool(eval), world.device)
+        return self._graphed(key, lambda: _GraphedMove(self, world, eval, capacity=cap))(world)
 
     @profiling.roctx
     def play(self, world, eval=False):
@@ -523,18 +549,29 @@ class _GraphedMove:
     graph is replayed, outputs are cloned out.  Network parameters are read in place, so training steps between
     replays are seen."""
 
-    def __init__(self, agent, world, eval, step=False):
+    def __init__(self, agent, world, eval, step=False, capacity=None):
         dev = world.device
-        self.board, self.seats = world.board.clone(), world.seats.clone()
+        n = world.n_envs
+        self.capacity = capacity if capacity is not None else n
+        assert self.capacity >= n and not (step and self.capacity != n)
+        if self.capacity == n:
+            self.board, self.seats = world.board.clone(), world.seats.clone()
+        else:                                              # rows beyond the caller's envs: empty boards, never searched
+            self.board = torch.zeros((self.capacity,) + tuple(world.board.shape[1:]), dtype=world.board.dtype, device=dev)
+            self.seats = torch.zeros((self.capacity,), dtype=world.seats.dtype, device=dev)
+            self.board[:n] = world.board; self.seats[:n] = world.seats
+        # the number of live rows, read by the search kernels on the device: rewritten before every replay
+        self.n_active = torch.full((1,), n, dtype=torch.int32, device=dev) if capacity is not None else None
         self.network = agent.network
         self.step = step
         kind = type(world)
         if hasattr(self.network, 'refresh_if_stale'):
             self.network.refresh_if_stale()
+        extra = {} if self.n_active is None else {'n_active': self.n_active}
 
         def run():
             w = kind(board=self.board, seats=self.seats)
-            d = agent._move(w, eval, {}, clone=False)      # __call__ clones the replay's outputs
+            d = agent._move(w, eval, extra, clone=False)   # __call__ clones the replay's outputs
             if not step:
                 return d
             new_world, transition = w.step(d.actions, check=False)
@@ -543,20 +580,28 @@ class _GraphedMove:
         with torch.cuda.device(dev):
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
+            # the warm-up draws random numbers; put the generators back so that WHEN a move gets captured (the arena captures
+            # one per capacity bucket as its batches shrink) does not show in the stream: a seeded run with captured moves
+            # draws what the same run without them draws
+            private = getattr(agent.kwargs.get('rng'), 'generator', None)
+            gens = [torch.cuda.default_generators[dev.index if dev.index is not None else torch.cuda.current_device()]] + ([private] if private is not None else [])
+            states = [g.get_state() for g in gens]
             with torch.cuda.stream(side):
                 run()                                   # warm-up: builds lookup tables, lets hipBLASLt pick kernels
             torch.cuda.current_stream().wait_stream(side)
+            for g, st in zip(gens, states):
+                g.set_state(st)
+            reserved = torch.cuda.memory_stats(dev)['reserved_bytes.all.allocated']     # cumulative: frees elsewhere cannot hide growth
             self.graph = torch.cuda.CUDAGraph()
             generator = getattr(agent.kwargs.get('rng'), 'generator', None)
             if generator is not None:
                 self.graph.register_generator_state(generator)      # a private generator's offsets must be graph-managed too
             with torch.cuda.graph(self.graph):
                 self.out = run()
+            # what this capture keeps alive -- the tree, its scratch, the block of uniforms: a capture allocates from a pool of
+            # its own, so the allocator's reserved bytes grow by exactly that pool (measured, not estimated from shapes)
+            self.nbytes = max(torch.cuda.memory_stats(dev)['reserved_bytes.all.allocated'] - reserved, self.board.nbytes + self.seats.nbytes)
         self.kind = kind
-        # what this capture keeps alive: the tree and its scratch (the dominant (B,T,A) arrays: logits, children, cpi, cca;
-        # boards; the MoveRng block), estimated from the shapes
-        B, A, T = world.n_envs, world.boardsize ** 2, int({**agent.kwargs}.get('n_nodes', 64))
-        self.nbytes = B * T * (A * 13 + 2 * T + 64)
 
     @staticmethod
     def _clone_all(*trees):
@@ -567,14 +612,20 @@ class _GraphedMove:
         return [t.map(lambda _: next(it)) for t in trees]
 
     def __call__(self, world):
+        n = world.n_envs
+        board, seats = (self.board, self.seats) if n == self.capacity else (self.board[:n], self.seats[:n])
         if (world.board.dtype == self.board.dtype and world.seats.dtype == self.seats.dtype and world.board.is_contiguous()
                 and world.seats.is_contiguous()):
-            _native.copy_many([self.board, self.seats], [world.board, world.seats])
+            _native.copy_many([board, seats], [world.board, world.seats])
         else:
-            self.board.copy_(world.board); self.seats.copy_(world.seats)
+            board.copy_(world.board); seats.copy_(world.seats)
+        if self.n_active is not None:
+            self.n_active.fill_(n)
         if hasattr(self.network, 'refresh_if_stale'):
             self.network.refresh_if_stale()    # in place, outside the graph: replays read the static f16 weight buffers
         self.graph.replay()
+        if n != self.capacity:
+            return self._clone_all(self.out.map(lambda t: t[:n]))[0]
         if not self.step:
             return self._clone_all(self.out)[0]
         d, w, t = self._clone_all(*self.out)

@@ -4,6 +4,8 @@
 The structs do what the reference's TensorProxy constructors do (boardlaw/cpp/common.h:27-44): hold references,
 demand contiguity (RuntimeError), exact dtypes (TypeError "expected Half got Float") and ndim.  The kernels run in
 libboardlaw_amd.so on the current HIP stream, unsynchronised, like the reference's launches."""
+import ctypes
+
 import torch
 
 from .. import _native
@@ -92,8 +94,8 @@ def descend(m, rands=None):
             rands = torch.rand_like(m.logits[:, :, 0])
         rands = _proxy(rands.contiguous(), torch.half, 2, 'rands')
         parents = m.seats.new_empty((B,)); actions = m.seats.new_empty((B,))
-        _native.check(_native.lib().bl_mcts_descend(
-            m.logits.data_ptr(), m.w.data_ptr(), m.n.data_ptr(), m.c_puct.data_ptr(), m.seats.data_ptr(),
+        _native.check(_native.lib().bl_mcts_descend_tuned(
+            ctypes.byref(_native.tune()), m.logits.data_ptr(), m.w.data_ptr(), m.n.data_ptr(), m.c_puct.data_ptr(), m.seats.data_ptr(),
             m.terminal.data_ptr(), m.children.data_ptr(), rands.data_ptr(), state.data_ptr(),
             _native.exp_table(dev).data_ptr(), B, T, A, S, parents.data_ptr(), actions.data_ptr(), _native.stream(dev)))
     return Descent(parents, actions)
@@ -107,8 +109,8 @@ def root(m):
     with torch.cuda.device(dev):
         state = _qrange(m, dev)
         probs = torch.empty((B, A), dtype=torch.half, device=dev)
-        _native.check(_native.lib().bl_mcts_root(
-            m.logits.data_ptr(), m.w.data_ptr(), m.n.data_ptr(), m.c_puct.data_ptr(), m.seats.data_ptr(),
+        _native.check(_native.lib().bl_mcts_root_tuned(
+            ctypes.byref(_native.tune()), m.logits.data_ptr(), m.w.data_ptr(), m.n.data_ptr(), m.c_puct.data_ptr(), m.seats.data_ptr(),
             m.terminal.data_ptr(), m.children.data_ptr(), state.data_ptr(), _native.exp_table(dev).data_ptr(),
             B, T, A, S, probs.data_ptr(), _native.stream(dev)))
     return probs

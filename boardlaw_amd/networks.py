@@ -288,11 +288,12 @@ class Inference:
             M = x0.shape[0]
             policy = torch.empty((M, NH - 1), dtype=torch.half, device=x0.device)
             value = torch.empty((M,), dtype=torch.half, device=x0.device)
-            _native.check(L.bl_mlp_forward_f16(x0.data_ptr(), M, K0, pk['w0'].data_ptr(), w[1].data_ptr(), pk['wb'].data_ptr(),
-                                               pk['bb'].data_ptr(), pk['al'].data_ptr(), pk['wh'].data_ptr(), pk['bh'].data_ptr(),
-                                               W, D, K0pad, NH, NHpad, policy.data_ptr(), value.data_ptr(), st))
+            with torch.cuda.device(x0.device):
+                _native.check(L.bl_mlp_forward_f16(x0.data_ptr(), M, K0, pk['w0'].data_ptr(), w[1].data_ptr(), pk['wb'].data_ptr(),
+                                                   pk['bb'].data_ptr(), pk['al'].data_ptr(), pk['wh'].data_ptr(), pk['bh'].data_ptr(),
+                                                   W, D, K0pad, NH, NHpad, policy.data_ptr(), value.data_ptr(), st))
             return policy, value
-        if self.fused and self._packed is not None and self.LAYERS_PLAN and x0.is_cuda:
+        if self.fused and self._packed is not None and self.LAYERS_PLAN and x0.is_cuda and self._packed['dims'][1] % 2 == 0:
             # wide network, small batch: a launch per Linear, each split over all CUs (bl_mlp_layers_f16), instead of the
             # library GEMMs + elementwise launches below -- 1024x8 on 1024 rows of 13x13: see DESIGN.md 4.4
             pk = self._packed
@@ -301,9 +302,10 @@ class Inference:
             policy = torch.empty((M, NH - 1), dtype=torch.half, device=x0.device)
             value = torch.empty((M,), dtype=torch.half, device=x0.device)
             scratch = torch.empty((2, M, W), dtype=torch.half, device=x0.device)
-            _native.check(L.bl_mlp_layers_f16(x0.data_ptr(), M, K0, pk['w0'].data_ptr(), w[1].data_ptr(), pk['wb'].data_ptr(),
-                                              pk['bb'].data_ptr(), pk['al'].data_ptr(), pk['wh'].data_ptr(), pk['bh'].data_ptr(),
-                                              W, D, K0pad, NH, NHpad, scratch.data_ptr(), policy.data_ptr(), value.data_ptr(), st))
+            with torch.cuda.device(x0.device):
+                _native.check(L.bl_mlp_layers_f16(x0.data_ptr(), M, K0, pk['w0'].data_ptr(), w[1].data_ptr(), pk['wb'].data_ptr(),
+                                                  pk['bb'].data_ptr(), pk['al'].data_ptr(), pk['wh'].data_ptr(), pk['bh'].data_ptr(),
+                                                  W, D, K0pad, NH, NHpad, scratch.data_ptr(), policy.data_ptr(), value.data_ptr(), st))
             return policy, value
         x = F.linear(x0, w[0], w[1])
         r = F.relu(x)

@@ -68,6 +68,20 @@ def sum_over_ranks(value, device=None):
     return float(t.item())
 
 
+def gather_over_ranks(value, device=None):
+    """Every rank's float through ONE all-reduce(SUM) of a (world + 1,) vector: slot r carries rank r's value, the last slot a
+    one per rank.  Returns (values per rank, ranks seen): the collective itself reports how many ranks took part."""
+    rank, world, _ = env_rank()
+    if not dist.is_initialized():
+        return [float(value)], 1
+    device = device or ('cuda' if dist.get_backend() == 'nccl' else 'cpu')
+    t = torch.zeros(world + 1, dtype=torch.float64, device=device)
+    t[rank] = value
+    t[world] = 1
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return [float(x) for x in t[:world].tolist()], int(round(float(t[world].item())))
+
+
 def merge_qrange(*states):
     """Element-wise unsigned MAX of q-range states (int32 storage of u32 words): the state of the union of the shards.
     This is the local form of allreduce_qrange."""

@@ -88,6 +88,17 @@ def run(worlds, network, n_steps, nodes=64, c_puct=1 / 16, lr=1e-3, buffer_len=6
                                           transitions=learning.half(transition)).detach())
         batches[i] = new_worlds
 
+    def refresh_actor():
+        # all actors share ONE inference plan whose static f16 / packed weight buffers are rewritten in place: do it here, on
+        # the learner's stream, BEFORE the actors' streams wait on that stream -- otherwise the first actor to move refreshes on
+        # its own stream while another replays a captured move that reads the same buffers
+        if hasattr(actor, 'refresh_if_stale'):
+            actor.refresh_if_stale()
+
+    if concurrent:
+        refresh_actor()
+        for s_ in streams:
+            s_.wait_stream(torch.cuda.current_stream(dev))
     for step in range(n_steps):
         while any(len(b) < buffer_len for b in buffers):
             for i in range(len(batches)):
@@ -106,6 +117,7 @@ def run(worlds, network, n_steps, nodes=64, c_puct=1 / 16, lr=1e-3, buffer_len=6
             if on_step is not None:
                 on_step(step, pl, vl)
         if concurrent:
+            refresh_actor()
             for s_ in streams:                                  # ... and the next moves see the updated weights (and freed blocks)
                 s_.wait_stream(torch.cuda.current_stream(dev))
     return batches if many else batches[0]

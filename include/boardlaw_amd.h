@@ -13,7 +13,8 @@
  *     launches on the current torch stream (boardlaw/cpp/kernels.cu:8-10); safe inside hipGraph capture
  *     (no allocation, no synchronisation, no host-side state);
  *   - return 0 on success, a negative BL_E* code otherwise (never throws); bl_strerror() describes it;
- *   - re-entrant and GIL-free: the library keeps no global mutable state.
+ *   - re-entrant and GIL-free: the library keeps no global mutable state and reads no environment variables; every
+ *     tuning choice is an explicit field of bl_tune_t, set by the caller (zero-initialised = the defaults).
  *
  * Shapes: B envs, T node slots per env, A actions (= board cells), S seats.
  */
@@ -33,6 +34,18 @@ extern "C" {
 #define BL_QRANGE_WORDS 4096 /* u32 words in one q-range state: 64 slots, one per 256 B, words 0/1 = {~enc(min), enc(max)} */
 
 typedef void* bl_stream_t; /* hipStream_t */
+
+/* Explicit tuning choices (all 0 = the library's defaults).  Results never depend on them -- only which of the
+ * parity-tested kernel variants runs. */
+typedef struct {
+    int fold_fast;     /* 1: bl_sim_expand pads its dependent DPP fold steps with ONE wait state instead of the ISA's two (30 % faster).
+                          Set it only for a device on which bl_selftest() returned 0; 0: the ISA-padded fold */
+    int expand_waves;  /* waves per env in bl_sim_expand: 0 = default (2); 1, 2, 4, or 21 = two nodes per wave */
+    int expand_deep;   /* speculative guesses only from this descent level on (default 0) */
+    int expand_legacy; /* 1: bl_sim_expand runs the general kernel on logits/children instead of the compacted rows */
+    int group;         /* lanes per env in the general kernels: 0 = heuristic (64), or 8 / 16 / 32 / 64 */
+    int mlp_no_xcd;    /* 1: bl_sim_infer_finish forms its 32-row tiles from consecutive envs instead of same-XCD envs */
+} bl_tune_t;
 
 int bl_abi_version(void);
 const char* bl_strerror(int code);
@@ -63,11 +76,21 @@ int bl_mcts_descend(const void* logits /*f16 (B,T,A)*/, const void* w /*f16 (B,T
                     int B, int T, int A, int S,
                     int16_t* parents_out /*(B)*/, int16_t* actions_out /*(B)*/, bl_stream_t stream);
 
+/* bl_mcts_descend with explicit tuning (`tune->group`: the narrower lanes-per-env kernels, kept for parity tests). */
+int bl_mcts_descend_tuned(const bl_tune_t* tune, const void* logits, const void* w, const int16_t* n, const void* c_puct,
+                          const int16_t* seats, const uint8_t* terminal, const int16_t* children, const void* rands,
+                          const uint32_t* qrange_state, const float* exp_table, int B, int T, int A, int S,
+                          int16_t* parents_out, int16_t* actions_out, bl_stream_t stream);
+
 /* ---- mctscuda.root(m) -> (B,A) f16 probabilities   (wrappers.cpp:32-38, cuda.cu:107-136) ------------------------- */
 int bl_mcts_root(const void* logits, const void* w, const int16_t* n, const void* c_puct, const int16_t* seats,
                  const uint8_t* terminal, const int16_t* children,
                  const uint32_t* qrange_state, const float* exp_table,
                  int B, int T, int A, int S, void* probs_out /*f16 (B,A)*/, bl_stream_t stream);
+
+int bl_mcts_root_tuned(const bl_tune_t* tune, const void* logits, const void* w, const int16_t* n, const void* c_puct,
+                       const int16_t* seats, const uint8_t* terminal, const int16_t* children, const uint32_t* qrange_state,
+                       const float* exp_table, int B, int T, int A, int S, void* probs_out, bl_stream_t stream);
 
 /* ---- mctscuda.backup(bk, leaves)   (wrappers.cpp:40-46, cuda.cu:205-248): mutates w and n in place -------------- */
 int bl_mcts_backup(const void* v /*f16 (B,T,S)*/, void* w /*f16 (B,T,S)*/, int16_t* n /*(B,T)*/,
@@ -137,6 +160,12 @@ typedef struct {
     int16_t* fav;        /* i16 (B,T) scratch or NULL: each node's most visited child (-1: none), maintained by bl_sim_expand as
                             the guess for its speculative batches (several levels of a deep descent evaluated at once, one per
                             wave); a hint only -- results never depend on it.  NULL: one level at a time */
+    bl_tune_t tune;      /* explicit tuning choices, zero = defaults */
+    const int32_t* n_active; /* DEVICE scalar or NULL (= B): only envs 0 .. *n_active-1 take part in a simulation -- bl_sim_expand,
+                            bl_sim_finish, bl_sim_infer_finish, bl_sim_backup and bl_sim_compact skip the others, which then add
+                            nothing to the q-range either.  What lets ONE captured move (arrays sized for B envs) serve the arena's
+                            masked calls of any size <= B (boardlaw/arena/common.py:88-93): the caller packs the live envs first
+                            and rewrites the scalar before each replay; results for the active envs equal a B = *n_active search */
 } bl_search_t;
 
 /* mcts/__init__.py:113-129 + hex/__init__.py:148-195 for simulation number `sim` (1..T-1):
@@ -226,13 +255,13 @@ int bl_sim_plant_root(const bl_search_t* s, const float* policy_raw, const float
  * logits[b,node,:]; for logits stored without one of the calls above (MCTS.plant_root's tensor assignment). */
 int bl_sim_compact(const bl_search_t* s, const int16_t* leaves /*(B) or NULL*/, bl_stream_t stream);
 
-/* Device self-test, call once per process outside any stream capture (synchronises `stream`).  bl_sim_expand's serial
- * folds pad every dependent DPP step with the 2 wait states the ISA asks for (`s_nop 1`); on gfx950 one (`s_nop 0`) is
- * measured to be enough and 30 % faster.  This runs both variants on 4096 waves x 108 random chains against a serial
- * sum and switches the library to the one-wait-state fold only if it reproduced every prefix total (and BL_FOLD_SAFE is
- * not set).  Returns the number of wrong totals of the fast variant (0 = in use), or a BL_E* code. */
+/* Device self-test of the one-wait-state fold: call once per DEVICE (with that device current), outside any stream capture
+ * (synchronises `stream`).  bl_sim_expand's serial folds pad every dependent DPP step with the 2 wait states the ISA asks for
+ * (`s_nop 1`); on gfx950 one (`s_nop 0`) is measured to be enough and 30 % faster.  This runs both variants on 4096 waves x
+ * 108 random chains against a serial sum.  Returns the number of wrong totals of the one-wait-state variant -- 0: the caller
+ * may set bl_tune_t.fold_fast = 1 for searches on this device -- or a BL_E* code (also when the ISA-padded fold itself is
+ * wrong).  The library stores nothing. */
 int bl_selftest(bl_stream_t stream);
-int bl_fold_variant(void);   /* 1: one-wait-state fold in use; 0: ISA-padded fold */
 
 /* MCTSAgent's action draw (mcts/__init__.py:221: Categorical(logits = log of the root distribution).sample()) by inverse CDF:
  * actions[b] = first action whose running total of probs[b,:] (f16, ascending, summed in f32) reaches uniforms[b] * total,

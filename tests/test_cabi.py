@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(L, s), f'{s} declared in the header but not exported'
         assert s in _native.SYMBOLS, f'{s} has no ctypes signature in boardlaw_amd/_native.py'
     assert sorted(_native.SYMBOLS) == syms
-    assert L.bl_abi_version() == 1
+    assert L.bl_abi_version() == 2
 
 
 def test_argument_validation_without_gpu():
@@ -40,7 +40,7 @@ def test_argument_validation_without_gpu():
     assert b'limits' in L.bl_strerror(-2)
 
 
-@pytest.mark.parametrize('ctype,mirror', [('bl_search_t', 'Search'), ('bl_copy_t', 'Copy')])
+@pytest.mark.parametrize('ctype,mirror', [('bl_search_t', 'Search'), ('bl_copy_t', 'Copy'), ('bl_tune_t', 'Tune')])
 def test_struct_layout_matches_the_header(tmp_path, ctype, mirror):
     """The header's structs as gcc lays them out from include/boardlaw_amd.h == their ctypes mirrors, field by field."""
     import subprocess
@@ -58,6 +58,15 @@ def test_struct_layout_matches_the_header(tmp_path, ctype, mirror):
     assert {k: int(v) for k, v in got.items()} == {n: getattr(cls, n).offset for n in names}
     if mirror == 'Copy':
         assert _native.COPY_MAX == int(re.search(r'#define BL_COPY_MAX (\d+)', open(os.path.join(ROOT, 'include', 'boardlaw_amd.h')).read()).group(1))
+
+
+def test_library_reads_no_environment():
+    """re-entrant, no global state -- every tuning choice is a bl_tune_t field set by the caller; the library
+    imports neither getenv nor secure_getenv (the BL_* switches live in the Python host layer, boardlaw_amd/_native.py: tune)."""
+    import subprocess
+    from boardlaw_amd import _native
+    undefined = subprocess.check_output(['nm', '-D', '--undefined-only', _native.LIBPATH]).decode()
+    assert 'getenv' not in undefined, [l for l in undefined.splitlines() if 'getenv' in l]
 
 
 def test_exp_table_is_host_libm(oracle):

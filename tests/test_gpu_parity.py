@@ -1014,7 +1014,7 @@ def test_fold_wait_states_under_load():
         steps += 6 * 4096 * sum((1, 2, 15, 16, 17, 31, 32, 33, 47, 48, 49, 54, 63, 64, 65, 80, 81, 96)) * 2   # both variants
     torch.cuda.synchronize()
     assert steps > 1e8
-    assert L.bl_fold_variant() == (0 if os.environ.get('BL_FOLD_SAFE') else 1)
+    assert _native.fold_fast(torch.device('cuda')) == (0 if os.environ.get('BL_FOLD_SAFE') else 1)
 
 
 @pytest.mark.parametrize('A,B', [(81, 4096), (9, 1000), (169, 512), (700, 64)])

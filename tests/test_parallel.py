@@ -91,6 +91,7 @@ def test_bench_gpus_flag_spawns_one_rank_per_gpu():
     import subprocess, sys
     d = _bench(['--gpus', '2', '--steps', '1', '--warmup', '0'], {'BENCH_DRY': '1', 'BENCH_BACKEND': 'gloo'})
     assert d['n_gpus'] == 2 and d['ms_per_step'] >= 20.      # rank 1 sleeps 20 ms: the MAX over ranks is reported
+    assert d['ranks_seen'] == 2 and d['per_rank_values'] == [1.0, 2.0]     # through the collective: both ranks took part
     assert _bench([], {'BENCH_DRY': '1'})['n_gpus'] == 1
     bad = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2'], env={**os.environ, 'WORLD_SIZE': '3', 'BENCH_DRY': '1'},
                          capture_output=True, text=True)
@@ -103,6 +104,7 @@ def test_bench_two_ranks_on_one_gpu():
     d = _bench(['--gpus', '2', '--steps', '2', '--warmup', '1', '--envs', '256', '--no-cpu-baseline'],
                {'BENCH_BACKEND': 'gloo', 'BENCH_FORCE_DEVICE': '0'})
     assert d['n_gpus'] == 2 and d['config']['parallelism'] == 'replicas x2' and d['value'] > 0
+    assert d['ranks_seen'] == 2 and len(d['per_rank_values']) == 2 and all(v > 0 for v in d['per_rank_values'])
     assert d['scaling'] == 'weak'
 
 
@@ -131,3 +133,15 @@ print('rccl ok')
 ''' % ROOT
     r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and 'rccl ok' in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
+
+
+def test_arena_sweep_fans_out_over_worker_processes():
+    """tools/arena_sweep.py (config 5's sweep, one job per board size on a pool of workers -- arena/neural.py:257-274's fan-out):
+    the dry run plays real matches with deterministic agents on CPU worlds in two worker processes and reports one JSON line."""
+    import json, subprocess, sys
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'arena_sweep.py'), '--workers', '2', '--boards', '3,5', '--envs', '16', '--repeat', '2'],
+                         env={**os.environ, 'ARENA_DRY': '1'}, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith('{')][-1])
+    assert d['matches'] == 4 and d['games'] == 64 and d['workers'] == 2 and d['dry_run'] and d['sims_per_sec'] > 0
+    assert out.stdout.count('board 5x5') == 2 and out.stdout.count('board 3x3') == 2

@@ -315,25 +315,67 @@ def test_chunk_evaluator_with_search_agents():
 
 
 @pytest.mark.gpu
-def test_arena_with_captured_moves_at_config_5_size():
-    """BASELINE config 5's shape: 2048 envs per board size, arena.evaluate's masked calls with graph=True agents.  Every round
-    has a new batch size, so every round captures a new move; the cache is bounded in bytes (least recently used first) and
-    the match still plays every game to the end."""
+@pytest.mark.parametrize('S,n', [(9, 1000), (9, 777), (7, 64), (9, 2048), (5, 3)])
+def test_masked_captured_move_equals_the_eager_masked_call(S, n):
+    """One move captured for a capacity bucket (2048 / 1024 / 64 rows) serves a call of n envs with the other rows switched off
+    on the device (bl_search_t.n_active): decisions identical, bit for bit, to the eager call on exactly those n envs under the
+    same seed -- same Dirichlet rows, same uniforms (torch's kernels give row i the same numbers whatever the batch size), and a
+    q-range over the n envs only.  Twice in a row: the second replay reuses the capture with another n."""
+    from boardlaw_amd import networks
+    from boardlaw_amd.hex import Hex
+    from boardlaw_amd.mcts import MCTSAgent, MoveRng
+    from test_reference_fixtures import EdgeAgent
+    torch.manual_seed(S)
+    worlds = Hex.initial(2048, S)
+    for k in range(S * S // 3):                                   # mid-game positions, different per env
+        v = worlds.valid
+        worlds, _ = worlds.step((torch.rand(v.shape, device='cuda') * v).argmax(-1))
+    net = networks.Inference(networks.FCModel(worlds.obs_space, worlds.action_space, width=256, depth=2).cuda(), fused=True)
+    eager = MCTSAgent(net, n_nodes=32, rng=MoveRng())
+    graphed = MCTSAgent(net, n_nodes=32, rng=MoveRng(), graph=True)
+    for m in (n, max(1, n // 2 + 1)):
+        sub = worlds[torch.randperm(2048, device='cuda')[:m]]
+        for ev in (True, False):
+            torch.manual_seed(100 + m); a = eager(sub, eval=ev)
+            torch.manual_seed(100 + m); b = graphed(sub, eval=ev)
+            for k in ('logits', 'prior', 'v', 'actions', 'n_leaves', 'n_sims'):
+                x, y = a[k], b[k]
+                assert x.shape == y.shape, k
+                if x.dtype == torch.half:
+                    x, y = x.view(torch.int16), y.view(torch.int16)
+                assert torch.equal(x, y), (k, m, ev)
+    assert len(graphed._graphs) <= 4          # (eval, not eval) x at most two capacity buckets
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('S', [7, 9, 11])
+def test_arena_at_config_5_size_captured_equals_eager(S):
+    """BASELINE config 5's shape: 2048 games per board size through arena.evaluate's masked calls, two 64-sim 512x4 search
+    agents.  With captured moves (one per capacity bucket, rows beyond the call switched off) the whole match -- every move of
+    every game -- is the eager match under the same seed: identical wins, moves and games per seat permutation; and the captures
+    are few (the batches shrink through the buckets) and within the cache's byte bound."""
     from boardlaw_amd import arena, networks
     from boardlaw_amd.hex import Hex
-    from boardlaw_amd.mcts import MCTSAgent
-    for S in (3, 5):
-        worlds = Hex.initial(2048, S)
-        pair = {}
-        for name in ('one', 'two'):
-            torch.manual_seed(len(pair))
-            net = networks.Inference(networks.FCModel(worlds.obs_space, worlds.action_space, width=256, depth=2).cuda(), fused=True)
-            pair[name] = MCTSAgent(net, graph=True, n_nodes=16)
-            pair[name].GRAPH_CACHE_BYTES = 48 << 20
-        results = arena.evaluate(worlds, pair)
-        assert sum(r.games for r in results) == 2048 and all(sum(r.wins) == r.games for r in results)
-        for a in pair.values():
-            assert 1 <= len(a._graphs) and sum(g.nbytes for g in a._graphs.values()) <= 48 << 20
+    from boardlaw_amd.mcts import MCTSAgent, MoveRng
+    nets = []
+    for i in range(2):
+        torch.manual_seed(i)
+        w0 = Hex.initial(1, S)
+        nets.append(networks.Inference(networks.FCModel(w0.obs_space, w0.action_space, width=512, depth=4).cuda(), fused=True))
+    results = {}
+    for mode in ('eager', 'graph'):
+        pair = {name: MCTSAgent(net, graph=(mode == 'graph'), n_nodes=64, rng=MoveRng()) for name, net in zip(('one', 'two'), nets)}
+        torch.manual_seed(7)
+        results[mode] = arena.evaluate(Hex.initial(2048, S), pair)
+        if mode == 'graph':
+            for a in pair.values():
+                assert 1 <= len(a._graphs) <= 8 and sum(g.nbytes for g in a._graphs.values()) <= a.GRAPH_CACHE_BYTES
+                # measured from the allocator, not a formula: at least the capture's children array (rows x T x A i16)
+                assert all(g.nbytes >= g.capacity * 64 * S * S * 2 for g in a._graphs.values()), [(g.capacity, g.nbytes) for g in a._graphs.values()]
+    for e, g in zip(results['eager'], results['graph']):
+        assert e.names == g.names and e.wins == g.wins and e.moves == g.moves and e.games == g.games, (e, g)
+    assert sum(r.games for r in results['graph']) == 2048 and all(sum(r.wins) == r.games for r in results['graph'])
+    assert all(r.moves >= r.games * (2 * S - 1) / 2 for r in results['graph'])
 
 
 @pytest.mark.gpu
@@ -375,3 +417,64 @@ def test_learner_step_on_gpu_matches_cpu_fp32():
     assert abs(pc - pg) <= 2e-3 * abs(pc) and abs(vc - vg) <= 2e-3 * max(abs(vc), 1e-3), (pc, pg, vc, vg)
     for k in sc:
         assert (sc[k] - sg[k]).abs().max() <= 2e-3, k
+
+
+# ------------------------------------------------------------------------------------------------ arena fan-out (neural.py:202-274)
+def test_chunk_jobs_cover_every_missing_pair_once():
+    """neural.py:205-232: diagonal blocks play their own pairs, skew blocks only the cross pairs; together every ordered pair
+    with games missing is played in exactly one job, and complete pairs in none."""
+    from boardlaw_amd import arena
+    names = [f'a{i}' for i in range(7)]
+    games = np.zeros((7, 7), int)
+    games[0, 1] = 4; games[5, 6] = 4; games[6, 5] = 4          # already complete
+    jobs = arena.chunk_jobs(games, names, n_envs_per=4, chunks=3)
+    assert set(jobs) == {(0, 0), (1, 1), (0, 1), (0, 2), (1, 2)}        # block (2,2) = {a6} alone has nothing to play
+    todo = np.zeros((7, 7), int)
+    for block_names, played in jobs.values():
+        idx = [names.index(n) for n in block_names]
+        todo[np.ix_(idx, idx)] += (played < 4)
+    want = (games < 4).astype(int); want[np.diag_indices(7)] = 0
+    assert np.array_equal(todo, want)
+
+
+def test_run_jobs_pool_and_serial():
+    from boardlaw_amd import arena
+    import pool_helpers
+    jobs = {k: (pool_helpers.square, (k,)) for k in range(7)}
+    assert dict(arena.run_jobs(jobs, n_workers=0)) == {k: k * k for k in range(7)}
+    env = os.environ.get('PYTHONPATH', '')
+    os.environ['PYTHONPATH'] = os.pathsep.join([os.path.dirname(os.path.abspath(__file__)), env])      # the spawned workers import pool_helpers
+    try:
+        assert dict(arena.run_jobs(jobs, n_workers=2)) == {k: k * k for k in range(7)}
+        with pytest.raises(RuntimeError, match='failed in its worker'):
+            dict(arena.run_jobs({0: (pool_helpers.square, ('x', 'y'))}, n_workers=1))
+    finally:
+        os.environ['PYTHONPATH'] = env
+
+
+def test_evaluate_gen_two_workers_equals_one_chunk_evaluator(oracle):
+    """The fan-out (two worker processes, blocks of two agents) plays exactly the games a single ChunkEvaluator over all four
+    agents plays: same wins and moves per ordered pair (deterministic agents; each pair's games do not depend on the others)."""
+    from boardlaw_amd import arena
+    import pool_helpers
+    names = ['e0', 'e1', 'e2', 'e3']
+    agents = {n: pool_helpers.edge_agent(n) for n in names}
+    ev = arena.ChunkEvaluator(pool_helpers.cpu_worlds, agents, None, n_envs_per=4, device='cpu')
+    single = []
+    while not ev.finished():
+        single.extend(ev.step())
+    env = os.environ.get('PYTHONPATH', '')
+    os.environ['PYTHONPATH'] = os.pathsep.join([os.path.dirname(os.path.abspath(__file__)), env])
+    try:
+        fanned, last = [], None
+        for results, stats in arena.evaluate_gen(pool_helpers.cpu_worlds, pool_helpers.edge_agent, np.zeros((4, 4), int), names=names,
+                                                 n_envs_per=4, chunks=2, n_workers=2):
+            fanned.extend(results); last = stats
+    finally:
+        os.environ['PYTHONPATH'] = env
+    key = lambda r: tuple(r.names)
+    assert sorted(map(key, fanned)) == sorted(map(key, single)) and len(fanned) == 12
+    a, b = {key(r): r for r in fanned}, {key(r): r for r in single}
+    for k in a:
+        assert tuple(a[k].wins) == tuple(b[k].wins) and a[k].moves == b[k].moves and a[k].games == 4
+    assert last.finished == last.total == 3 and last.matchups == 12 and last.games == 48

@@ -33,15 +33,18 @@ selfplay(5, 64, 16, 16, 4, 'config 1')
 selfplay(9, 4096, 64, 512, 4, 'config 2 (bench.py is the measurement)')
 selfplay(13, 1024, 256, 1024, 8, 'config 4, per GPU')
 for S in (3, 5, 7, 9, 11):
-    worlds = Hex.initial(2048, S)
-    pair = {}
-    for name in ('one', 'two'):
-        torch.manual_seed(len(pair))
-        net = networks.Inference(networks.FCModel(worlds.obs_space, worlds.action_space, 512, 4).cuda(), fused=True)
-        pair[name] = MCTSAgent(net, graph=False, n_nodes=64)
-    torch.cuda.synchronize(); t0 = time.time()
-    res = arena.evaluate(worlds, pair)
-    torch.cuda.synchronize(); dt = time.time() - t0
-    moves = sum(r.moves for r in res)
-    print(f'config 5, per GPU: arena {S}x{S}, 2048 games, two 64-sim agents (512x4): {dt:.2f} s, {sum(r.games for r in res) / dt:.0f} games/s, '
-          f'{moves * 64 / dt / 1e6:.2f} M sims/s over {moves:.0f} moves', flush=True)
+    for mode in ('eager', 'captured'):
+        pair = {}
+        for name in ('one', 'two'):
+            torch.manual_seed(len(pair))
+            w0 = Hex.initial(1, S)
+            net = networks.Inference(networks.FCModel(w0.obs_space, w0.action_space, 512, 4).cuda(), fused=True)
+            pair[name] = MCTSAgent(net, graph=(mode == 'captured'), n_nodes=64, rng=MoveRng())
+        for rep in range(2):          # captured: the first match captures one move per capacity bucket, the second replays them
+            worlds = Hex.initial(2048, S)
+            torch.cuda.synchronize(); t0 = time.time()
+            res = arena.evaluate(worlds, pair)
+            torch.cuda.synchronize(); dt = time.time() - t0
+        moves = sum(r.moves for r in res)
+        print(f'config 5, per GPU: arena {S}x{S}, 2048 games, two 64-sim agents (512x4), {mode} moves: {dt:.2f} s, {sum(r.games for r in res) / dt:.0f} games/s, '
+              f'{moves * 64 / dt / 1e6:.2f} M sims/s over {moves:.0f} moves', flush=True)
