@@ -68,7 +68,13 @@ class Inference:
     raw() are bit-identical to FCModel.raw under autocast (tests/test_gpu_parity.py::test_inference_plan_matches_autocast)."""
 
     wants_half_obs = True
-    ROOT_FUSED_MIN_ROWS = 2048
+    # The root evaluation's plan must not depend on the batch size: a search's result for an env is a function of that env, the
+    # random stream and the batch's q-range only -- so a captured move padded to a capacity bucket (MCTSAgent(pad=True), the
+    # arena's masked calls) gives the bits of the eager call on exactly those envs.  bl_root_mlp_f32 computes every row in a
+    # fixed order whatever M is; the library GEMMs it replaces pick their kernels (and summation orders) by M.  Below ~2048 rows
+    # of 512x4 the kernel is no faster than the GEMMs (its 16-row workgroups do not fill the chip) and for 1024x8 on 1024 rows
+    # it is ~0.3 ms slower per move (of 46 ms): the price of the invariance.  Raise to trade it back.
+    ROOT_FUSED_MIN_ROWS = 0
     # bl_mlp_forward_f16's time is one workgroup's chain: every 32-row workgroup streams ALL the weights through its CU's L1
     # (64 B/clk).  Up to FUSED_ALWAYS_BYTES of weights (512x4: 2.4 MB, 28 us) that beats a launch per Linear at any batch size;
     # beyond it (1024x8: 17.9 MB, 170 us) only once the batch gives FUSED_MIN_TILES workgroups.  Below that every Linear is
@@ -223,8 +229,8 @@ class Inference:
         obs = worlds.obs
         x0 = obs.reshape(obs.shape[0], -1).float().contiguous()
         L, st = _native.lib(), _native.stream(x0.device)
-        # bl_root_mlp_f32 takes 16 rows per workgroup through all layers: it beats the library GEMMs once the batch fills
-        # at least half of the 256 CUs (102 vs 135 us at 4096 rows of 512x4; 64 workgroups of 1024x8 are 3x slower)
+        # bl_root_mlp_f32 takes 16 rows per workgroup through all layers (102 vs 135 us for the library GEMMs at 4096 rows of
+        # 512x4); used at every batch size, see ROOT_FUSED_MIN_ROWS
         if self.fused and self._root_packed is not None and x0.is_cuda and x0.shape[0] >= self.ROOT_FUSED_MIN_ROWS:
             rp = self._root_packed
             W, K0, K0pad, D, NH, NHpad = rp['dims']

@@ -478,3 +478,39 @@ def test_evaluate_gen_two_workers_equals_one_chunk_evaluator(oracle):
     for k in a:
         assert tuple(a[k].wins) == tuple(b[k].wins) and a[k].moves == b[k].moves and a[k].games == 4
     assert last.finished == last.total == 3 and last.matchups == 12 and last.games == 48
+
+
+def _big_worker(rank, world, port, out):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from boardlaw_amd import parallel, networks, heads
+    torch.set_num_threads(2)
+    parallel.init('gloo')
+    torch.manual_seed(0)
+    net = networks.FCModel(heads.Tensor((13, 13, 2)), heads.Masked(169), width=1024, depth=8)      # config 4's network: 8.9 M parameters
+    gen = torch.Generator(); gen.manual_seed(100 + rank)
+    for p in net.parameters():
+        p.grad = torch.randn(p.shape, generator=gen)
+    mine = torch.cat([p.grad.flatten() for p in net.parameters()]).clone()
+    parallel.allreduce_gradients(net)
+    flat = torch.cat([p.grad.flatten() for p in net.parameters()])
+    out.put((rank, mine.double().sum().item(), flat.double().sum().item(), flat[::100003].clone().numpy(), flat.numel()))
+    torch.distributed.destroy_process_group()
+
+
+def test_two_rank_gradient_allreduce_at_config_4_network_size():
+    """parallel.allreduce_gradients on the 1024x8 network of config 4 (one flat 35 MB fp32 bucket) over two gloo ranks: every rank
+    ends with the mean of the two ranks' gradients, element for element."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context('spawn')
+    out = ctx.Queue()
+    procs = [ctx.Process(target=_big_worker, args=(r, world, port, out)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = {r[0]: r[1:] for r in (out.get(timeout=300) for _ in range(world))}
+    for p in procs:
+        p.join(120); assert p.exitcode == 0
+    assert res[0][3] == res[1][3] > 8_000_000
+    assert np.array_equal(res[0][2], res[1][2])                                       # both ranks hold the same averaged gradient
+    assert abs(res[0][1] - (res[0][0] + res[1][0]) / 2) <= 1e-3 * max(1., abs(res[0][1]))  # and it is the mean of the two

@@ -20,9 +20,10 @@ for p in (ROOT, os.path.join(ROOT, 'tests')):
         sys.path.insert(0, p)
 
 
-def search_match(S, n_envs, nodes, width, depth, graph):
+def search_match(S, n_envs, nodes, width, depth, graph, start_at=None):
     """One arena match between two search agents on this worker's device; the second of two back-to-back matches is timed
-    (the first captures the moves / warms the library up)."""
+    (the first captures the moves / warms the library up).  start_at (wall clock): every worker's timed match starts then, so
+    that concurrent matches really overlap."""
     import torch
     from boardlaw_amd import arena, networks
     from boardlaw_amd.hex import Hex
@@ -34,6 +35,8 @@ def search_match(S, n_envs, nodes, width, depth, graph):
         pair[name] = MCTSAgent(networks.Inference(networks.FCModel(w0.obs_space, w0.action_space, width, depth).cuda(), fused=True),
                                graph=graph, n_nodes=nodes, rng=MoveRng())
     for rep in range(2):
+        if rep == 1 and start_at is not None and time.time() < start_at:
+            time.sleep(start_at - time.time())
         torch.cuda.synchronize(); t0 = time.time()
         res = arena.evaluate(Hex.initial(n_envs, S), pair)
         torch.cuda.synchronize(); dt = time.time() - t0
@@ -61,6 +64,8 @@ def main():
     ap.add_argument('--depth', type=int, default=4)
     ap.add_argument('--repeat', type=int, default=1, help='matches per board size')
     ap.add_argument('--eager', action='store_true', help='no captured moves')
+    ap.add_argument('--together', type=float, default=0., help='seconds from now at which every worker starts its timed match (use with one '
+                                                              'job per worker to measure matches that overlap completely); 0: as they come')
     args = ap.parse_args()
     dry = os.environ.get('ARENA_DRY') == '1'
     import torch
@@ -71,7 +76,8 @@ def main():
     workers = args.workers if args.workers is not None else max(n_gpus, 1)
     boards = [int(x) for x in args.boards.split(',')]
     fn = dry_match if dry else search_match
-    jobs = {(S, r): (fn, (S, args.envs, args.nodes, args.width, args.depth, not args.eager)) for r in range(args.repeat) for S in sorted(boards, reverse=True)}
+    start_at = time.time() + args.together if args.together > 0 else None
+    jobs = {(S, r): (fn, (S, args.envs, args.nodes, args.width, args.depth, not args.eager, start_at)) for r in range(args.repeat) for S in sorted(boards, reverse=True)}
     os.environ['PYTHONPATH'] = os.pathsep.join([ROOT, os.path.join(ROOT, 'tests'), os.path.dirname(os.path.abspath(__file__)), os.environ.get('PYTHONPATH', '')])
     t0 = time.time()
     done = []
