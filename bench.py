@@ -102,6 +102,48 @@ def cpu_baseline(seconds_budget=24.0):
         return {'value': None, 'unit': 'sims/s', 'cores': 0, 'kind': 'port', 'sample': f'unavailable: {type(e).__name__}: {e}'}
 
 
+def measure_traffic(kernel='sim_expand', timeout=240):
+    """HBM-side bytes per launch of the dominant kernel, observed in THIS run: two separate rocprofv3 --pmc passes (FETCH_SIZE,
+    WRITE_SIZE; --kernel-trace only, no other trace domain) over `bench.py --steps 2 --warmup 1 --timed-only`, from /tmp.
+    Units and corrections as /opt/skills/guides/MI355X_MICROARCH.md (HBM) prescribes and profiles/r02_calib_* confirmed on this
+    device: both counters are in KB; on gfx950 FETCH_SIZE tallies the 128-B requests of coalesced reads at 64 B, i.e. reports
+    half of their bytes (this kernel's reads are rows and lane-parallel slot statistics: coalesced), WRITE_SIZE is exact.
+    traffic = 2 x FETCH_SIZE + WRITE_SIZE.  Returns (bytes or None, description)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    if shutil.which('rocprofv3') is None:
+        return None, 'rocprofv3 not on PATH'
+    means = {}
+    for counter in ('FETCH_SIZE', 'WRITE_SIZE'):
+        out = tempfile.mkdtemp(prefix=f'bl_pmc_{counter}_', dir='/tmp')
+        cmd = ['rocprofv3', '--kernel-trace', '--pmc', counter, '-d', out, '--output-format', 'csv', '--', sys.executable,
+               os.path.abspath(__file__), '--steps', '2', '--warmup', '1', '--timed-only']
+        env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK')}
+        env['TMPDIR'] = '/tmp'
+        try:
+            subprocess.run(cmd, cwd='/tmp', env=env, capture_output=True, timeout=timeout, check=True)
+            total, n = 0.0, 0
+            for f in glob.glob(os.path.join(out, '**', '*counter_collection.csv'), recursive=True):
+                with open(f) as fh:
+                    for row in csv.DictReader(fh):
+                        if kernel in row.get('Kernel_Name', '') and row.get('Counter_Name') == counter:
+                            total += float(row['Counter_Value']); n += 1
+            if n == 0:
+                return None, f'no {counter} rows for *{kernel}* in the rocprofv3 output'
+            means[counter] = (total / n, n)
+        except Exception as e:  # pragma: no cover
+            return None, f'rocprofv3 --pmc {counter} failed: {type(e).__name__}: {str(e)[:200]}'
+        finally:
+            shutil.rmtree(out, ignore_errors=True)
+    (f_kb, n_f), (w_kb, n_w) = means['FETCH_SIZE'], means['WRITE_SIZE']
+    return (2 * f_kb + w_kb) * 1024, (f'measured in this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes of `bench.py --steps 2 '
+                                       f'--warmup 1 --timed-only`, mean over {n_f} / {n_w} launches: FETCH_SIZE {f_kb:.1f} KB (x2: gfx950 counts coalesced 128-B requests '
+                                       f'at 64 B), WRITE_SIZE {w_kb:.1f} KB')
+
+
 def respawn_per_gpu(args):
     """`python bench.py --gpus N` with N > 1 and no launcher around it: re-executes itself as N ranks, one process per GPU
     (the reference's model: boardlaw/main.py:202-209, rebar/parallel.py:28-36), under torch.distributed.run on 127.0.0.1.
@@ -154,11 +196,13 @@ def main():
     ap.add_argument('--width', type=int, default=WIDTH, help='exploration only: FCModel width (metric: 512)')
     ap.add_argument('--depth', type=int, default=DEPTH, help='exploration only: FCModel depth (metric: 4)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-traffic', action='store_true', help='skip the two rocprofv3 --pmc passes behind roofline.traffic')
     ap.add_argument('--plain-network', action='store_true', help='run the nn.Module under autocast instead of the fp16 inference plan')
     ap.add_argument('--torch-gemms', action='store_true', help='keep the Linears as torch (hipBLASLt) GEMMs instead of the fused MFMA kernel')
     ap.add_argument('--timed-only', action='store_true', help='for profilers: only capture, warm-up and the timed moves; prints a reduced line')
     ap.add_argument('--no-reference-rng', action='store_true', help='skip the second timed region (torch rand_like per simulation)')
     ap.add_argument('--no-two-actors', action='store_true', help='skip the two-actors-per-GPU region')
+    ap.add_argument('--no-soak', action='store_true', help='skip the 200 extra moves behind value_after_self_play_drift')
     ap.add_argument('--eager', action='store_true', help='launch kernel by kernel instead of replaying a HIP graph per move')
     args = ap.parse_args()
     respawn_per_gpu(args)
@@ -281,6 +325,21 @@ def main():
             torch.cuda.current_stream().wait_stream(s_)
         del actors, pair
 
+    drifted = None
+    if world == 1 and not args.eager and default_shape and not args.no_soak:
+        # the timed region above starts from freshly pre-mixed boards; self-play drifts to its own mix of positions (shorter games
+        # restart, trees get deeper): the same measurement after 150 further moves, reported beside the headline
+        w4 = worlds
+        for _ in range(150):
+            w4 = move(w4)
+        barrier()
+        t3 = time.perf_counter()
+        for _ in range(50):
+            w4 = move(w4)
+        barrier()
+        drifted = {'sims_per_sec': args.envs * NODES * 50 / (time.perf_counter() - t3), 'moves_before': args.warmup + args.steps + 150, 'moves_timed': 50}
+        del w4
+
     if rank == 0:
         A, S = BOARD * BOARD, 2
         if not args.eager:
@@ -315,12 +374,13 @@ def main():
         per_launch = expand_bytes_per_env(A, S, d, k) * args.envs
         achieved = per_launch / (kernel_us * 1e-6) / 1e9
         traffic, traffic_source = None, None
-        tpath = os.path.join(ROOT, 'profiles', 'r02_traffic.json')
-        if args.envs == ENVS and default_shape and os.path.exists(tpath):
-            # NOT measured in this run: HBM-side bytes per launch from separate rocprofv3 --pmc passes of this very command
-            # (FETCH_SIZE, WRITE_SIZE; calibration and corrections in profiles/README.md), committed with the round
-            traffic = json.load(open(tpath))['traffic_bytes_per_launch']
-            traffic_source = 'static: profiles/r02_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `python bench.py`)'
+        if args.envs == ENVS and default_shape and not args.no_traffic:
+            traffic, traffic_source = measure_traffic()
+            tpath = os.path.join(ROOT, 'profiles', 'r02_traffic.json')
+            if traffic is None and os.path.exists(tpath):
+                # fallback, NOT measured in this run: the same two passes as committed with round 2
+                traffic = json.load(open(tpath))['traffic_bytes_per_launch']
+                traffic_source = f'static: profiles/r02_traffic.json ({traffic_source})'
         out = {
             'metric': 'mcts_sims_per_sec', 'value': value, 'unit': 'sims/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps, 'higher_is_better': True,
@@ -335,7 +395,10 @@ def main():
                                    else 'a launch per Linear, bl_mlp_layers_f16 (autocast rounding points), + bl_sim_finish' if not agent.network.prefers_fused(args.envs)
                                    else 'fused MFMA kernel bl_sim_infer_finish (autocast rounding points; <= 1 f16 ulp vs autocast)') + '; root evaluation fp32',
                        'rng': 'MoveRng: stream-identical to the reference protocol (torch generator; Dirichlet and Categorical are torch\'s own calls; the T-1 rand_like (B,T) f16 draws of a move come from ONE launch, bl_rand_block, that evaluates the Philox counters those calls would use and advances the generator by what they would consume -- tests/test_rng_stream.py)',
-                       'value_reference_rng_protocol': value_torch_rng,
+                       'rng_stream_identical_to_reference_protocol': True,
+                       'value_reference_rng_protocol': value,          # the headline IS on the reference's stream (MoveRng above)
+                       'value_rand_like_call_by_call': value_torch_rng,  # TorchRng: the same stream drawn with T-1 separate launches
+                       'value_after_self_play_drift': drifted,
                        'search_kernels_only': search_only,
                        'two_actors_per_gpu': two_actors,
                        'network_mfma_bound_sims_per_sec': 2.5e15 / (2 * (2 * A * WIDTH + DEPTH * WIDTH * WIDTH + WIDTH * (A + 1))),
