@@ -343,16 +343,6 @@ __global__ void __launch_bounds__(BL_WAVE * NW, (RMAX <= 3 ? 8 : 4)) sim_expand2
     int t = 0, parent = 0, action = -1, nlev = 0, sel_e = 0, evals = 0;
     int tinfo = pick(info, 0);
     bool live = true;
-    // The board the expansion will step is the LAST node's of the descent -- one of the current batch's nodes.  Wave 0 (which
-    // expands) requests the boards of all of them at the head of every batch, ahead of its row loads: they arrive with the rows,
-    // and the expansion starts without a memory round trip of its own.
-    constexpr int CB = (32 * RMAX + 63) / 64;          // board bytes per lane
-    int pb[NW][CB];
-    int pbk = -1;                                      // which of the batch's nodes the descent ended on (-1: no batch ran)
-#pragma unroll
-    for (int k = 0; k < NW; k++)
-#pragma unroll
-        for (int c = 0; c < CB; c++) pb[k][c] = 0;
     for (int batch = 0; batch < T; batch++) {
         if (!live || t == -1 || ((tinfo >> 17) & 1) || nlev >= T) break;
         // the nodes of this batch: the current one and its guessed continuation
@@ -364,16 +354,6 @@ __global__ void __launch_bounds__(BL_WAVE * NW, (RMAX <= 3 ? 8 : 4)) sim_expand2
             if (nlev >= deep_thresh && u[k - 1] != -1 && !((uinfo[k - 1] >> 17) & 1)) {
                 u[k] = pick(fav, u[k - 1]);
                 if (u[k] != -1) uinfo[k] = pick(info, u[k]);
-            }
-        }
-        if (wave == 0) {
-#pragma unroll
-            for (int k = 0; k < NW; k++) {
-                if (u[k] != -1) {
-                    const uint8_t* brd = s.boards + (envbase + u[k]) * A;
-#pragma unroll
-                    for (int c = 0; c < CB; c++) if (lane + 64 * c < A) pb[k][c] = brd[lane + 64 * c];
-                }
             }
         }
         int my = -1, myinfo = 0;
@@ -397,7 +377,7 @@ __global__ void __launch_bounds__(BL_WAVE * NW, (RMAX <= 3 ? 8 : 4)) sim_expand2
                 const int node = u[k];
                 if (path && wave == 0 && lane == 0) path[1 + nlev] = (int16_t)node;
                 nlev++;
-                parent = node; sel_e = s_k; pbk = k;
+                parent = node; sel_e = s_k;
                 if (COUNT && wave == 0 && lane == 0) {
                     unsigned long long* e = counters + 12 * (long)b;
                     const int iters = in_k & 0xff;
@@ -439,18 +419,9 @@ __global__ void __launch_bounds__(BL_WAVE * NW, (RMAX <= 3 ? 8 : 4)) sim_expand2
         s.relation[envbase + leaf] = (int16_t)action;
         if (nxt == -1 && nlev > 0) ((uint16_t*)(s.cca + (envbase + parent) * A + sel_e))[1] = (uint16_t)leaf;   // the compacted row's child field
     }
-    const int seat = (pick(info, parent) >> 16) & 1;          // worlds.seats[b, parent], already in the slot registers
-    if (pbk >= 0) {
-#pragma unroll
-        for (int k = 0; k < NW; k++)
-            if (k == pbk) {
-#pragma unroll
-                for (int c = 0; c < CB; c++) if (lane + 64 * c < A) cells[lane + 64 * c] = (uint8_t)pb[k][c];
-            }
-    } else {
-        const uint8_t* src = s.boards + (envbase + parent) * A;
-        for (int a = lane; a < A; a += 64) cells[a] = src[a];
-    }
+    const int seat = s.seats[envbase + parent];
+    const uint8_t* src = s.boards + (envbase + parent) * A;
+    for (int a = lane; a < A; a += 64) cells[a] = src[a];
     __syncthreads();
     const int win = hex_step_group<64>(cells, S, seat, action, true, lane);
     // Hex.step tail, hex/__init__.py:183-190
