@@ -6,7 +6,7 @@ LIB = os.path.join(ROOT, 'tools', 'micro', 'libboardlaw_clk.so')
 if '--build' in sys.argv:
     sys.path.insert(0, ROOT)
     from boardlaw_amd import build as b
-    subprocess.check_call([b.shutil.which('hipcc') or '/opt/rocm/bin/hipcc'] + b.FLAGS + ['-DBL_MLP_CLK'] + b.SOURCES + ['-o', LIB])
+    subprocess.check_call([b.shutil.which('hipcc') or '/opt/rocm/bin/hipcc'] + b.FLAGS + ['-shared', '-DBL_MLP_CLK'] + b.SOURCES + ['-o', LIB])
     sys.exit(0)
 import numpy as np, torch
 sys.path.insert(0, ROOT)

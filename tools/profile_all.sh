@@ -1,6 +1,6 @@
 #!/bin/bash
 # usage (GPU box, repo root): tools/profile_all.sh <tag>  -- everything profiles/ holds for a round, into gpurun_out/<tag>/
-tag=${1:-r02}; out=gpurun_out/$tag; mkdir -p $out
+tag=${1:-r03}; out=gpurun_out/$tag; mkdir -p $out
 python bench.py > $out/bench.json 2> $out/bench.err
 STEPS=20 WARM=3 bash tools/profile_round.sh $tag > /dev/null 2>&1
 bash tools/profile_pmc.sh $tag > /dev/null 2>&1
