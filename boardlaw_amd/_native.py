@@ -17,7 +17,7 @@ _vp, _i = ctypes.c_void_p, ctypes.c_int
 
 class Tune(ctypes.Structure):
     """bl_tune_t: explicit tuning choices (zero = defaults); results never depend on them."""
-    _fields_ = [(k, _i) for k in ('fold_fast', 'expand_waves', 'expand_deep', 'expand_legacy', 'group', 'mlp_no_xcd')]
+    _fields_ = [(k, _i) for k in ('fold_fast', 'expand_waves', 'expand_deep', 'expand_legacy', 'group', 'mlp_no_xcd', 'lazy_init')]
 
 
 class Search(ctypes.Structure):
@@ -60,7 +60,7 @@ SYMBOLS = {
     'bl_sim_compact': (_i, [ctypes.POINTER(Search), _vp, _vp]),
     'bl_draw_actions': (_i, [_vp, _vp, _vp, _i, _i, _vp]),
     'bl_copy_many': (_i, [_vp, _i, _vp]),
-    'bl_rand_block': (_i, [_vp, _i, ctypes.c_long, ctypes.c_long, _i, ctypes.c_ulonglong, ctypes.c_ulonglong, ctypes.c_uint, _i, _vp]),
+    'bl_rand_block': (_i, [_vp, _i, ctypes.c_long, ctypes.c_long, _i, ctypes.c_ulonglong, ctypes.c_ulonglong, ctypes.c_uint, _i, _i, _vp]),
     'bl_selftest': (_i, [_vp]),
 }
 

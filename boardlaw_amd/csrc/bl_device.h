@@ -206,7 +206,24 @@ struct Search {
     float* cpi; uint32_t* cca; int16_t* nk;      // compacted policy rows, see compact_store()
     int16_t* fav;                                // (B,T) most visited child of a node, a hint for bl_expand.hip's speculative batches
     const int32_t* n_active;                     // device scalar or null: envs >= *n_active sit the simulation out
+    int lazy;                                    // bl_tune_t.lazy_init: bl_sim_expand #sim gives slot `sim` its reset values
 };
+
+// bl_tune_t.lazy_init, called by one wave of env b at the end of bl_sim_expand #sim: what MCTS.__init__ (mcts/__init__.py:43-67)
+// put into slot `sim` of the big arrays, written now instead of by bl_sim_init -- children[b,sim,:] = -1 always (a new node has
+// no children yet; an unused slot never gets any); when the simulation re-visited a terminal node instead of creating node `sim`,
+// also logits[b,sim,:] = NaN and the root world in worlds[b,sim] (a created node gets its logits from the finish step and its
+// board from the expansion).
+__device__ __forceinline__ void lazy_slot_reset(const Search& s, long envbase, int sim, int A, bool created, int lane, int lanes = 64) {
+    int16_t* ch = s.children + (envbase + sim) * A;
+    for (int a = lane; a < A; a += lanes) ch[a] = (int16_t)-1;
+    if (!created) {
+        uint16_t* lg = s.logits + (envbase + sim) * A;
+        const uint8_t* root = s.boards + envbase * A;
+        uint8_t* brd = s.boards + (envbase + sim) * A;
+        for (int a = lane; a < A; a += lanes) { lg[a] = 0x7e00u; brd[a] = root[a]; }
+    }
+}
 
 // number of envs that take part (bl_search_t.n_active); a scalar load
 __device__ __forceinline__ int active_envs(const Search& s) { return s.n_active ? __builtin_amdgcn_readfirstlane(*s.n_active) : s.B; }

@@ -413,6 +413,7 @@ __global__ void __launch_bounds__(BL_WAVE * NW, (RMAX <= 3 ? 8 : 4)) sim_expand2
     // ---- leaves = children[envs, parents, actions]; leaves[leaves == -1] = sim   (mcts/__init__.py:117-122)
     const int nxt = t;
     const int leaf = (nxt == -1) ? sim : nxt;
+    if (s.lazy) lazy_slot_reset(s, envbase, sim, A, nxt == -1, lane);
     if (lane == 0) {
         s.children[(envbase + parent) * A + action] = (int16_t)leaf;
         s.parents[envbase + leaf] = (int16_t)parent;
@@ -694,6 +695,7 @@ __global__ void __launch_bounds__(BL_WAVE) sim_expand3_kernel(Search s, int sim,
     // ---- leaves = children[envs, parents, actions]; leaves[leaves == -1] = sim   (mcts/__init__.py:117-122); Hex.step + observe
     const int nxt = t;
     const int leaf = (nxt == -1) ? sim : nxt;
+    if (s.lazy) lazy_slot_reset(s, envbase, sim, A, nxt == -1, lane);
     if (lane == 0) {
         s.children[(envbase + parent) * A + action] = (int16_t)leaf;
         s.parents[envbase + leaf] = (int16_t)parent;

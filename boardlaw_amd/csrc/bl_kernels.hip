@@ -682,6 +682,7 @@ __global__ void __launch_bounds__(BL_WAVE) sim_expand_kernel(Search s, int sim, 
     const int leaf = (nxt == -1) ? sim : nxt;
     const long envbase = (long)b * T;
     int seat = 0;
+    if (act && s.lazy) lazy_slot_reset(s, envbase, sim, A, nxt == -1, gl, G);
     if (act) {
         if (gl == 0) {
             s.children[(envbase + parent) * A + action] = (int16_t)leaf;
@@ -1017,10 +1018,12 @@ __device__ __forceinline__ void grid_fill(void* p, size_t nbytes, uint16_t pat) 
 // to execute on the first replay only with the ROCm runtime PyTorch bundles, so the reset is a kernel, not memsets.)
 __global__ void __launch_bounds__(256) sim_init_kernel(Search s, const uint8_t* root_board, const int32_t* root_seats) {
     const size_t B = s.B, T = s.T, A = (size_t)s.S * s.S;
-    grid_fill(s.children, B * T * A * 2, 0xffff);
+    if (!s.lazy) {                                // lazy: bl_sim_expand #sim resets slot sim's rows, node 0's are written below / by the root evaluation
+        grid_fill(s.children, B * T * A * 2, 0xffff);
+        grid_fill(s.logits, B * T * A * 2, 0x7e00);   // f16 NaN, mcts/__init__.py:56
+    }
     grid_fill(s.parents, B * T * 2, 0xffff);
     grid_fill(s.relation, B * T * 2, 0xffff);
-    grid_fill(s.logits, B * T * A * 2, 0x7e00);   // f16 NaN, mcts/__init__.py:56
     grid_fill(s.v, B * T * 2 * 2, 0x7e00);
     grid_fill(s.w, B * T * 2 * 2, 0);
     grid_fill(s.n, B * T * 2, 0);
@@ -1039,6 +1042,17 @@ __global__ void __launch_bounds__(256) sim_init_worlds_kernel(Search s, const ui
     const int b = blockIdx.x, T = s.T, A = s.S * s.S;
     for (int a = threadIdx.x; a < A; a += blockDim.x) root[a] = root_board[(long)b * A + a];
     __syncthreads();
+    if (s.lazy) {
+        // node 0 only: its board, its (empty) children row and -- until the root evaluation stores the real ones -- NaN logits
+        for (int a = threadIdx.x; a < A; a += blockDim.x) {
+            s.boards[(long)b * T * A + a] = root[a];
+            s.children[(long)b * T * A + a] = (int16_t)-1;
+            s.logits[(long)b * T * A + a] = 0x7e00u;
+        }
+        const int seat0 = root_seats[b];
+        for (int t = threadIdx.x; t < T; t += blockDim.x) s.seats[(long)b * T + t] = seat0;
+        return;
+    }
     const long bytes = (long)T * A;
     uint8_t* dst = s.boards + (long)b * bytes;            // torch allocations are >= 16-B aligned and T*A*b keeps 1-B steps:
     const long head = (4 - ((uintptr_t)dst & 3)) & 3;     // bytes before the first aligned word of this env's block
@@ -1352,7 +1366,7 @@ static Search to_search(const bl_search_t* s) {
     return Search{(uint16_t*)s->logits, (uint16_t*)s->v, (uint16_t*)s->w, s->n, s->children, s->parents, s->relation,
                   (uint16_t*)s->rewards, s->terminal, s->boards, s->seats, (const uint16_t*)s->c_puct, s->qrange,
                   s->exp_table, s->B, s->T, s->boardsize, s->obs_f16, s->path, s->order, s->prio_thresh,
-                  s->cpi, s->cca, s->nk, s->fav, s->n_active};
+                  s->cpi, s->cca, s->nk, s->fav, s->n_active, s->tune.lazy_init};
 }
 
 static int sim_expand_impl(const bl_search_t* s, int sim, const void* rands, int16_t* leaves, void* obs, uint8_t* valid,

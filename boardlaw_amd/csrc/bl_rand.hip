@@ -62,13 +62,57 @@ __global__ void __launch_bounds__(256) rand_block_kernel(uint16_t* out, int n_ca
     }
 }
 
+// The same draws for a search's descents on (B,T) tensors, written only where a descent can read them: descend #c+1 looks at
+// rands[b, t] for nodes t <= c (the ones that exist).  torch's geometry is one element per thread with element idx = b*T + t, so
+// in the kernel above no wave could skip anything (a wave's 64 elements are one env's slots).  Here a wave takes ONE slot t of 64
+// envs -- waves of slots > c never start their Philox rounds, half of a move's -- and the tile goes through LDS so that the
+// stores are whole row segments.  Same counters, same conversion: the written elements carry the same bits.
+// grid: x over groups of 64 envs, y = call c; 256 threads = 4 waves = 4 slots at a time.
+__global__ void __launch_bounds__(256) rand_block_slots_kernel(uint16_t* out, int n_calls, int B, int T, unsigned long long seed_or_ptr,
+                                                               unsigned long long offset_or_ptr, unsigned int intragraph, int captured) {
+    extern __shared__ uint16_t tile[];              // [64][T + 2]
+    unsigned long long seed = seed_or_ptr, offset = offset_or_ptr;
+    if (captured) {
+        seed = (unsigned long long)*(const long long*)seed_or_ptr;
+        offset = (unsigned long long)*(const long long*)offset_or_ptr + intragraph;
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, ld = T + 2;
+    const int c = blockIdx.y, e = blockIdx.x * 64 + lane;
+    const int nslots = c + 1 < T ? c + 1 : T;
+    const uint2 key{(unsigned)seed, (unsigned)(seed >> 32)};
+    const unsigned long long ctr = offset / 4 + (unsigned long long)c;            // loops == 1: one Philox block per element
+    for (int t0 = 0; t0 < nslots; t0 += 4) {
+        const int t = t0 + wave;
+        if (t < nslots && e < B) {
+            const unsigned long long idx = (unsigned long long)e * T + t;
+            const uint4 r = philox4x32_10(uint4{(unsigned)ctr, (unsigned)(ctr >> 32), (unsigned)idx, (unsigned)(idx >> 32)}, key);
+            tile[lane * ld + t] = uniform_f16(r.x);
+        }
+    }
+    __syncthreads();
+    uint16_t* dst = out + (long)c * B * T;
+    for (int el = wave; el < 64; el += 4) {
+        const int env = blockIdx.x * 64 + el;
+        if (env >= B) break;
+        for (int t = lane; t < nslots; t += 64) dst[(long)env * T + t] = tile[el * ld + t];
+    }
+}
+
 }  // namespace bl
 
 extern "C" int bl_rand_block(void* out, int n_calls, long numel, long threads, int loops, unsigned long long seed_or_ptr,
-                             unsigned long long offset_or_ptr, unsigned int offset_intragraph, int captured, bl_stream_t stream) {
+                             unsigned long long offset_or_ptr, unsigned int offset_intragraph, int captured, int only_slots_upto_call,
+                             bl_stream_t stream) {
     if (!out || n_calls <= 0 || numel <= 0 || threads <= 0 || threads % 256 != 0 || loops <= 0) return BL_EINVAL;
     if ((long)loops * threads * 4 < numel || (long)(loops - 1) * threads * 4 >= numel) return BL_EINVAL;     // loops = (numel-1)/(4*threads)+1
     if (captured && (!seed_or_ptr || !offset_or_ptr)) return BL_EINVAL;
+    if (only_slots_upto_call < 0 || (only_slots_upto_call > 0 && numel % only_slots_upto_call != 0)) return BL_EINVAL;
+    if (only_slots_upto_call > 0 && loops == 1 && threads >= numel && only_slots_upto_call <= 1024 && n_calls <= 65535) {
+        const int T = only_slots_upto_call, B = (int)(numel / T);
+        hipLaunchKernelGGL(bl::rand_block_slots_kernel, dim3((unsigned)((B + 63) / 64), (unsigned)n_calls), dim3(256), (size_t)64 * (T + 2) * 2,
+                           (hipStream_t)stream, (uint16_t*)out, n_calls, B, T, seed_or_ptr, offset_or_ptr, offset_intragraph, captured);
+        return hipGetLastError() == hipSuccess ? BL_OK : BL_ELAUNCH;
+    }
     long gy = (long)n_calls * loops;
     if (gy > 65535) gy = 65535;
     hipLaunchKernelGGL(bl::rand_block_kernel, dim3((unsigned)(threads / 256), (unsigned)gy), dim3(256), 0, (hipStream_t)stream, (uint16_t*)out,

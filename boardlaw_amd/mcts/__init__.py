@@ -63,12 +63,14 @@ class MoveRng(TorchRng):
         captured moves CONCURRENTLY (several actors on one GPU, each on its own stream) need a generator each: a captured
         graph reads its Philox offset from a tensor the generator owns and refills before every replay, so two graphs on
         one generator race for it (and, being the same graph, would draw the same numbers)."""
-        self.block, self.i, self.generator, self.expected = None, 0, generator, 0
+        self.block, self.i, self.generator, self.expected, self.slots_upto_call = None, 0, generator, 0, False
 
-    def start(self, n_calls, like=None):
+    def start(self, n_calls, like=None, slots_upto_call=False):
         """Announces that `n_calls` rand_like draws of one shape follow (a move's descents).  Nothing is drawn yet: the
-        reference's Dirichlet comes first in the stream (MCTS.initialize), the block is cut at the first rand_like."""
-        self.block, self.i, self.expected = None, 0, n_calls
+        reference's Dirichlet comes first in the stream (MCTS.initialize), the block is cut at the first rand_like.
+        slots_upto_call: the consumer is a search's descents on (B,T) tensors -- descend #c+1 can only read slots t <= c (the
+        nodes that exist), so the block kernel leaves the others unwritten (half the Philox work; the written ones unchanged)."""
+        self.block, self.i, self.expected, self.slots_upto_call = None, 0, n_calls, slots_upto_call
 
     def _draw_block(self, x):
         threads, loops = torch_rand_geometry(x.numel(), x.device)
@@ -76,8 +78,9 @@ class MoveRng(TorchRng):
         with torch.cuda.device(x.device):
             seed, offset, intragraph, captured = _native.philox_state(gen, self.expected * 4 * loops)
             block = torch.empty((self.expected,) + tuple(x.shape), dtype=torch.half, device=x.device)
+            tri = x.shape[-1] if (self.slots_upto_call and x.ndim == 2) else 0
             _native.check(_native.lib().bl_rand_block(block.data_ptr(), self.expected, x.numel(), threads, loops, seed, offset, intragraph,
-                                                      captured, _native.stream(x.device)))
+                                                      captured, tri, _native.stream(x.device)))
         return block
 
     def rand_like(self, x):
@@ -158,11 +161,13 @@ class LeafWorlds:
 class MCTS:
 
     def __init__(self, world, n_nodes=64, c_puct=1 / 16, noise_eps=.25, alpha_scale=10, fused=None, rng=None,
-                 count=False, obs_half=False, qrange_sync=None, fuse_finish=True, n_active=None):
+                 count=False, obs_half=False, qrange_sync=None, fuse_finish=True, n_active=None, lazy=False):
         """c_puct high: concentrates on prior; c_puct low: concentrates on value (mcts/__init__.py:29-33).
         n_active (fused path): a one-element int32 DEVICE tensor -- only the first n_active[0] envs of `world` are searched, the
         rest sit the simulations out and add nothing to the q-range (bl_search_t.n_active): what lets one captured move of B
-        envs serve masked calls of any size <= B."""
+        envs serve masked calls of any size <= B.
+        lazy (fused path): the (B,T,A) arrays get their reset values slot by slot from the simulations instead of from one 105 MB
+        fill per move (bl_tune_t.lazy_init); identical arrays once all n_nodes - 1 simulations have run -- what mcts() does."""
         from .. import hex as hexmod
         self.device = world.device
         self.n_envs = world.n_envs
@@ -219,6 +224,7 @@ class MCTS:
                 exp_table=self._exp.data_ptr(), B=B, T=T, boardsize=bs, obs_f16=int(obs_half),
                 path=self._path.data_ptr(), cpi=self._cpi.data_ptr(), cca=self._cca.data_ptr(), nk=self._nk.data_ptr(),
                 fav=self._fav.data_ptr(), tune=_native.tune(dev))
+            self._search.tune.lazy_init = int(bool(lazy))
             if n_active is not None:
                 assert n_active.dtype == torch.int32 and n_active.numel() == 1 and n_active.device == world.board.device
                 self._n_active = n_active                      # kept alive: the kernels read it through the pointer
@@ -418,9 +424,11 @@ class MCTS:
 
 def mcts(worlds, network, **kwargs):
     kwargs.setdefault('obs_half', bool(getattr(network, 'wants_half_obs', False)))
+    kwargs.setdefault('lazy', True)         # a whole search follows: every slot gets its reset values on the way
     m = MCTS(worlds, **kwargs)
     if hasattr(m.rng, 'start') and m.n_nodes > 1:
-        m.rng.start(m.n_nodes - 1)          # announces the move's T-1 descend draws; drawn after the root's Dirichlet
+        # announces the move's T-1 descend draws; drawn after the root's Dirichlet
+        m.rng.start(m.n_nodes - 1, slots_upto_call=m.fused) if isinstance(m.rng, MoveRng) else m.rng.start(m.n_nodes - 1)
     if hasattr(network, 'refresh_if_stale') and not (worlds.device.type == 'cuda' and torch.cuda.is_current_stream_capturing()):
         network.refresh_if_stale()     # picks up optimiser steps; a captured move is refreshed by its replayer instead
     m.initialize(network)

@@ -45,6 +45,11 @@ typedef struct {
     int expand_legacy; /* 1: bl_sim_expand runs the general kernel on logits/children instead of the compacted rows */
     int group;         /* lanes per env in the general kernels: 0 = heuristic (64), or 8 / 16 / 32 / 64 */
     int mlp_no_xcd;    /* 1: bl_sim_infer_finish forms its 32-row tiles from consecutive envs instead of same-XCD envs */
+    int lazy_init;     /* 1: bl_sim_init resets only what a search reads before writing (the (B,T) arrays, node 0's rows); the big
+                          (B,T,A) API arrays get their reset values slot by slot from bl_sim_expand #sim (children[b,sim,:] = -1;
+                          if the simulation creates no node also logits[b,sim,:] = NaN and the root board in boards[b,sim]).  After
+                          all T-1 simulations every array equals the eager reset's; before that, slots > sim are undefined: for
+                          callers that always run a whole search (MCTSAgent) */
 } bl_tune_t;
 
 int bl_abi_version(void);
@@ -281,6 +286,9 @@ int bl_draw_actions(const void* probs /*f16 (B,A)*/, const float* uniforms /*(B)
  * kernels during HIP-graph capture) and offset_intragraph is added to the loaded offset; else they are the values. */
 int bl_rand_block(void* out /*f16 (n_calls, numel)*/, int n_calls, long numel, long threads, int loops,
                   unsigned long long seed_or_ptr, unsigned long long offset_or_ptr, unsigned int offset_intragraph, int captured,
+                  int only_slots_upto_call /* 0: every element; T > 0: the tensors are (B,T) rows and call c writes only the
+                  elements (b, t <= c) -- all descend #c+1 can read (nodes 0..c exist then); the rest stays unwritten.  Halves
+                  the Philox work of a move; the written elements are the same bits */,
                   bl_stream_t stream);
 
 /* Up to BL_COPY_MAX device-to-device copies in ONE launch (`items` is HOST memory, read before the call returns).  Copy k

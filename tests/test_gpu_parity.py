@@ -1141,3 +1141,37 @@ def test_inference_plan_selection():
     torch.manual_seed(0)
     b = mcts(w, wide, n_nodes=8)                       # the same search through bl_sim_infer_finish
     assert (to_np(a.stats.n)[:, 0] == 14).all() and (to_np(b.stats.n)[:, 0] == 14).all()
+
+
+@pytest.mark.parametrize('S,B,T', [(9, 512, 64), (5, 100, 16), (13, 64, 96)])
+def test_lazy_reset_equals_the_eager_reset(S, B, T):
+    """bl_tune_t.lazy_init (what mcts() uses): the (B,T,A) arrays get their reset values slot by slot from the simulations
+    instead of from bl_sim_init's fills.  After a whole search every array -- including the slots of simulations that re-visited
+    a terminal node and created nothing (children -1, logits NaN, the root world) -- equals the eagerly reset search's, from
+    buffers that were poisoned beforehand."""
+    from boardlaw_amd import networks
+    from boardlaw_amd.hex import Hex
+    from boardlaw_amd.mcts import MCTS, TorchRng
+    torch.manual_seed(S * 100 + T)
+    world = Hex.initial(B, S)
+    for k in range(S * S - 4):                                  # nearly full boards: many terminal re-visits
+        v = world.valid
+        world, _ = world.step((torch.rand(v.shape, device=DEV) * v).argmax(-1))
+    net = networks.Inference(networks.FCModel(world.obs_space, world.action_space, width=256, depth=2).to(DEV), fused=True)
+    runs = []
+    for lazy in (False, True):
+        torch.manual_seed(9)
+        m = MCTS(world, n_nodes=T, rng=TorchRng(), lazy=lazy, obs_half=True)
+        if lazy:      # the lazy reset leaves slots >= 1 of the big arrays untouched: poison them, nothing of it may survive the search
+            m.tree.children[:, 1:] = 7; m.decisions.logits[:, 1:] = 7.; m.worlds.board[:, 1:] = 7
+        m.initialize(net)
+        for _ in range(T - 1):
+            m.simulate(net)
+        runs.append(m)
+    a, b = runs
+    unused = (to_np(a.tree.parents)[:, 1:] == -1).sum()
+    for name, x, y in [('children', a.tree.children, b.tree.children), ('logits', a.decisions.logits, b.decisions.logits),
+                       ('boards', a.worlds.board, b.worlds.board), ('seats', a.worlds.seats, b.worlds.seats), ('n', a.stats.n, b.stats.n),
+                       ('w', a.stats.w, b.stats.w), ('parents', a.tree.parents, b.tree.parents), ('v', a.decisions.v, b.decisions.v)]:
+        assert np.array_equal(to_np(x) if x.dtype != torch.half else bits16(x), to_np(y) if y.dtype != torch.half else bits16(y)), name
+    assert unused > 0, 'the case must contain simulations that created no node'

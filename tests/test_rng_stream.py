@@ -135,3 +135,21 @@ def test_seeded_agent_under_move_rng_is_the_torch_rng_agent(S, B, T, width, dept
                 x, y = x.view(torch.int16), y.view(torch.int16)
             assert torch.equal(x, y), k
         assert torch.equal(ba, bb) and torch.equal(sa, sb)
+
+
+def test_rand_block_for_descents_writes_the_slots_a_descent_can_read():
+    """slots_upto_call (what mcts() asks for on the fused path): call c's tensor carries the reference's uniforms in the slots
+    t <= c -- every node that exists at descend #c+1 -- and the generator still ends where T-1 rand_like calls end."""
+    from boardlaw_amd.mcts import MoveRng
+    B, T = 777, 64
+    like = torch.empty((B, T), dtype=torch.half, device=DEV)
+    torch.manual_seed(5)
+    want = torch.stack([torch.rand_like(like) for _ in range(T - 1)])
+    end = _offset()
+    torch.manual_seed(5)
+    rng = MoveRng()
+    rng.start(T - 1, slots_upto_call=True)
+    got = torch.stack([rng.rand_like(like) for _ in range(T - 1)])
+    assert _offset() == end
+    mask = torch.arange(T, device=DEV)[None, None, :] <= torch.arange(T - 1, device=DEV)[:, None, None]      # (T-1, 1, T): t <= c
+    assert torch.equal(torch.where(mask, got, torch.zeros_like(got)).view(torch.int16), torch.where(mask, want, torch.zeros_like(want)).view(torch.int16))
