@@ -639,6 +639,30 @@ def test_actor_learner_loop_runs_and_learns_something(inference, graph):
     assert (after - before).abs().max() > 0
 
 
+def test_actor_learner_step_at_config_4_per_gpu_shape():
+    """BASELINE config 4's per-GPU shape through the actor/learner loop: 13x13, 1024 envs, 256 sims/move, FCModel 1024x8, captured
+    moves with the plan's own choice of network kernels (a launch per Linear), one learner step under AMP with the gradient
+    all-reduce in the path (a no-op group of one here; two ranks at this network's size: tests/test_training.py).  Losses finite,
+    every parameter tensor moved, the worlds still legal."""
+    from boardlaw_amd import hex, networks, training
+    torch.manual_seed(0)
+    worlds = hex.Hex.initial(1024, 13, device=DEV)
+    net = networks.FCModel(worlds.obs_space, worlds.action_space, width=1024, depth=8).to(DEV)
+    with torch.no_grad():
+        for p_ in net.parameters():
+            if p_.ndim == 0:
+                p_.fill_(0.3)
+    before = [p.detach().clone() for p in net.parameters()]
+    log = []
+    out = training.run(worlds, net, n_steps=1, nodes=256, buffer_len=3, graph=True, inference='fused',
+                       on_step=lambda i, pl, vl: log.append((float(pl), float(vl))))
+    torch.cuda.synchronize()
+    assert len(log) == 1 and np.isfinite(log[0]).all() and log[0][0] > 0
+    assert all((a.detach() - b).abs().max() > 0 for a, b in zip(net.parameters(), before))
+    stones = (out.board != 0).flatten(1).sum(-1)
+    assert out.n_envs == 1024 and int(stones.max()) <= 3 and int(stones.min()) >= 0 and bool(out.valid.any(-1).all())
+
+
 def test_actor_learner_loop_with_two_actors_on_one_gpu():
     """training.run with a list of env batches: two actors searching concurrently (own stream, own generator, captured
     moves, fused plans), one learner step per actor chunk.  Same seed => same losses, bit for bit, whatever the overlap on
