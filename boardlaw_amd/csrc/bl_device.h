@@ -100,14 +100,6 @@ __device__ __forceinline__ void ieee_div_n(const float (&a)[N], const float (&b)
     }
 }
 
-// Reduce the 64 qrange slots: every lane of the wave returns {lo, hi}.  transition_q, cuda.cu:101-105.
-__device__ __forceinline__ void load_qrange(const uint32_t* qr, float& lo, float& hi) {
-    const int lane = threadIdx.x & 63;
-    uint32_t a = qr[BL_QSTRIDE * lane], b = qr[BL_QSTRIDE * lane + 1];
-    a = gmaxu<64>(a); b = gmaxu<64>(b);
-    lo = dec(~a); hi = dec(b);
-}
-
 __host__ __device__ __forceinline__ int al16(int x) { return (x + 15) & ~15; }
 
 template <int CTRL, int RM>
@@ -121,9 +113,17 @@ __device__ __forceinline__ int wave_sum_i32(int v) {     // integer: any order i
     v += dpp_i<0x142, 0xa>(0, v); v += dpp_i<0x143, 0xc>(0, v);
     return __builtin_amdgcn_readlane(v, 63);
 }
+// One v_max_f32_dpp per stage (the update_dpp + fmaxf form costs four VALU instructions per stage: a copy, the DPP move, fmaxf's
+// canonicalising max and the max), ISA wait states in front of every DPP read.  Lanes without a source keep their value.  Operands are
+// never NaN here, so v_max_f32 is fmaxf bit for bit.
 __device__ __forceinline__ float wave_max_f32(float v) {   // max: any order is exact
-    v = fmaxf(v, dpp_f<0x111, 0xf>(v, v)); v = fmaxf(v, dpp_f<0x112, 0xf>(v, v)); v = fmaxf(v, dpp_f<0x114, 0xf>(v, v));
-    v = fmaxf(v, dpp_f<0x118, 0xf>(v, v)); v = fmaxf(v, dpp_f<0x142, 0xa>(v, v)); v = fmaxf(v, dpp_f<0x143, 0xc>(v, v));
+    asm volatile("s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+                 "s_nop 1" : "+v"(v));
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
@@ -132,6 +132,14 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
     v = max(v, (uint32_t)dpp_i<0x142, 0xa>(0, (int)v)); v = max(v, (uint32_t)dpp_i<0x143, 0xc>(0, (int)v));
     return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
 }
+// Reduce the 64 qrange slots: every lane of the wave returns {lo, hi}.  transition_q, cuda.cu:101-105.
+__device__ __forceinline__ void load_qrange(const uint32_t* qr, float& lo, float& hi) {
+    const int lane = threadIdx.x & 63;
+    uint32_t a = qr[BL_QSTRIDE * lane], b = qr[BL_QSTRIDE * lane + 1];
+    a = wave_max_u32(a); b = wave_max_u32(b);       // DPP reductions + readlane (the shuffle butterflies were 12 LDS round trips)
+    lo = dec(~a); hi = dec(b);
+}
+
 __device__ __forceinline__ float readlane_f(float v, int lane) {
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
 }

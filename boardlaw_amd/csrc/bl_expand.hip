@@ -320,7 +320,8 @@ __global__ void __launch_bounds__(BL_WAVE * NW, (RMAX <= 3 ? 8 : 4)) sim_expand2
             if (r < R) {
                 const bool isS = lowhalf != ((r & 1) != 0);
                 const bool pos = in[r] && isS && term[r] > 0.f;
-                const unsigned long long hit = __ballot(pos && x[r] >= rnd), anyp = __ballot(pos);
+                // (ballot_w64 on the compare itself: __ballot(bool) goes through a 0/1 VGPR and a second compare)
+                const unsigned long long hit = __builtin_amdgcn_ballot_w64(pos && x[r] >= rnd), anyp = __builtin_amdgcn_ballot_w64(pos);
                 if (sel_r < 0 && hit) { sel_r = r; sel_lane = __builtin_ctzll(hit); }
                 if (anyp) { last_r = r; last_lane = 63 - __builtin_clzll(anyp); }
             }
@@ -632,7 +633,8 @@ __global__ void __launch_bounds__(BL_WAVE) sim_expand3_kernel(Search s, int sim,
         for (int r = 0; r < RB; r++) {
             if (r < R) {
                 const bool pos = in[r] && isS && term[r] > 0.f;
-                const unsigned long long hit = __ballot(pos && x[r] >= rnd), anyp = __ballot(pos);
+                // (ballot_w64 on the compare itself: __ballot(bool) goes through a 0/1 VGPR and a second compare)
+                const unsigned long long hit = __builtin_amdgcn_ballot_w64(pos && x[r] >= rnd), anyp = __builtin_amdgcn_ballot_w64(pos);
 #pragma unroll
                 for (int k = 0; k < 2; k++) {
                     const uint32_t h = (uint32_t)(hit >> (32 * k)) & 0xffffu, p = (uint32_t)(anyp >> (32 * k)) & 0xffffu;
