@@ -374,7 +374,7 @@ def main():
         per_launch = expand_bytes_per_env(A, S, d, k) * args.envs
         achieved = per_launch / (kernel_us * 1e-6) / 1e9
         traffic, traffic_source = None, None
-        if args.envs == ENVS and default_shape and not args.no_traffic:
+        if args.envs == ENVS and default_shape and not args.no_traffic and world == 1:      # a per-GPU figure: the N = 1 line carries it
             traffic, traffic_source = measure_traffic()
             tpath = os.path.join(ROOT, 'profiles', 'r02_traffic.json')
             if traffic is None and os.path.exists(tpath):
