@@ -1077,6 +1077,33 @@ __global__ void sim_init_qrange_kernel(Search s) {
     s.qrange[BL_QWORDS * 1 + 1] = enc(0.f);
 }
 
+// The three launches above as ONE, a workgroup per env (the lazy-reset move's form: 35 -> ~10 us of kernel time per move).  Env b's
+// workgroup writes its own T slots of every (B,T) array, node 0's board / children / logits rows, its share of the q-range rows'
+// zeroes -- and the thread whose share holds row 1's first slot writes descend #1's range {0, 0} there instead of zero, so no
+// ordering between the zeroing and that write is needed.
+__global__ void __launch_bounds__(256) sim_init_env_kernel(Search s, const uint8_t* root_board, const int32_t* root_seats) {
+    const int b = blockIdx.x, T = s.T, A = s.S * s.S, tid = threadIdx.x;
+    const long eb = (long)b * T;
+    const int seat0 = root_seats[b];
+    for (int t = tid; t < T; t += 256) {
+        s.parents[eb + t] = (int16_t)-1; s.relation[eb + t] = (int16_t)-1;
+        *(uint32_t*)(s.v + (eb + t) * 2) = 0x7e007e00u; *(uint32_t*)(s.w + (eb + t) * 2) = 0u;
+        s.n[eb + t] = 0; *(uint32_t*)(s.rewards + (eb + t) * 2) = 0u; s.terminal[eb + t] = 0;
+        if (s.nk) s.nk[eb + t] = 0;
+        if (s.fav) s.fav[eb + t] = (int16_t)-1;
+        s.seats[eb + t] = seat0;
+    }
+    if (s.path && tid == 0) s.path[(long)b * (T + 2)] = 0;                  // no previous descent
+    for (int a = tid; a < A; a += 256) {
+        s.boards[eb * A + a] = root_board[(long)b * A + a];
+        s.children[eb * A + a] = (int16_t)-1;
+        s.logits[eb * A + a] = 0x7e00u;                                    // until the root evaluation stores the real ones
+    }
+    const size_t words = (size_t)(T + 1) * BL_QWORDS, step = (size_t)gridDim.x * 256;
+    for (size_t i = (size_t)b * 256 + tid; i < words; i += step)
+        s.qrange[i] = i == (size_t)BL_QWORDS ? ~enc(0.f) : (i == (size_t)BL_QWORDS + 1 ? enc(0.f) : 0u);
+}
+
 // MCTS.n_leaves (mcts/__init__.py:151-152): nodes that exist (parents != -1) and have no child.  A node has a child
 // exactly when some node names it as its parent, so the (B,T) parents array suffices.  One wave per env; LDS flags.
 __global__ void __launch_bounds__(BL_WAVE) sim_n_leaves_kernel(const int16_t* parents, long long* out, int T) {
@@ -1543,6 +1570,10 @@ int bl_sim_init(const bl_search_t* s, const uint8_t* root_board, const int32_t* 
     if (rc) return rc;
     if (!root_board || !root_seats) return BL_EINVAL;
     hipStream_t hs = (hipStream_t)stream;
+    if (s->tune.lazy_init) {             // the (B,T,A) arrays are reset slot by slot by the simulations: everything else in one launch
+        hipLaunchKernelGGL(sim_init_env_kernel, dim3(s->B), dim3(256), 0, hs, to_search(s), root_board, root_seats);
+        return check_launch();
+    }
     hipLaunchKernelGGL(sim_init_kernel, dim3(2048), dim3(256), 0, hs, to_search(s), root_board, root_seats);
     hipLaunchKernelGGL(sim_init_worlds_kernel, dim3(s->B), dim3(256), 0, hs, to_search(s), root_board, root_seats);
     hipLaunchKernelGGL(sim_init_qrange_kernel, dim3(1), dim3(1), 0, hs, to_search(s));
