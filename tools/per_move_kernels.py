@@ -1,5 +1,5 @@
 """Per-move (not per-simulation) kernel time in a rocprofv3 --kernel-trace database of `bench.py --timed-only`: the trace is
-cut into moves at bl::sim_init_kernel (the first launch of every search); the last `moves` complete moves -- graph replays --
+cut into moves at bl::sim_init_kernel / bl::sim_init_env_kernel (the first launch of every search); the last `moves` complete moves -- graph replays --
 are averaged.  Usage: python tools/per_move_kernels.py <db> <moves> [--sequence]   (--sequence: also the last move's launches outside the
 simulations, in order)"""
 import sqlite3, sys
@@ -8,7 +8,7 @@ c = sqlite3.connect(sys.argv[1]); want = int(float(sys.argv[2]))
 cols = [r[1] for r in c.execute("pragma table_info(kernels)")]
 name = 'name' if 'name' in cols else 'kernel_name'
 rows = c.execute(f"select {name}, start, end from kernels order by start").fetchall()
-cuts = [i for i, r in enumerate(rows) if 'sim_init_kernel' in r[0]]
+cuts = [i for i, r in enumerate(rows) if 'sim_init_kernel' in r[0] or 'sim_init_env_kernel' in r[0]]
 spans = list(zip(cuts[:-1], cuts[1:]))[-want:]
 tot, calls, wall, sims = defaultdict(float), defaultdict(float), 0.0, 0.0
 for a, b in spans:
