@@ -17,7 +17,7 @@ _vp, _i = ctypes.c_void_p, ctypes.c_int
 
 class Tune(ctypes.Structure):
     """bl_tune_t: explicit tuning choices (zero = defaults); results never depend on them."""
-    _fields_ = [(k, _i) for k in ('fold_fast', 'expand_waves', 'expand_deep', 'expand_legacy', 'group', 'mlp_no_xcd', 'lazy_init')]
+    _fields_ = [(k, _i) for k in ('fold_fast', 'expand_waves', 'expand_deep', 'expand_legacy', 'group', 'mlp_no_xcd', 'lazy_init', 'expand_envs', 'expand_help')]
 
 
 class Search(ctypes.Structure):
@@ -119,7 +119,8 @@ def tune(device=None):
     parity tests of the kernel variants); the library itself reads no environment."""
     return Tune(fold_fast=fold_fast(device) if device is not None else 0, expand_waves=_env_int('BL_EXPAND_WAVES'),
                 expand_deep=_env_int('BL_EXPAND_DEEP'), expand_legacy=_env_int('BL_EXPAND_LEGACY'), group=_env_int('BL_FORCE_GROUP'),
-                mlp_no_xcd=int(os.environ.get('BL_MLP_XCD', '1') == '0'))
+                mlp_no_xcd=int(os.environ.get('BL_MLP_XCD', '1') == '0'), expand_envs=_env_int('BL_EXPAND_ENVS'),
+                expand_help=_env_int('BL_EXPAND_HELP'))
 
 
 GENLIBPATH = os.path.join(HERE, 'libbl_torchgen.so')
@@ -134,6 +135,11 @@ def philox_state(generator, increment):
     if _genlib is None:
         if not os.path.exists(GENLIBPATH):
             raise NativeError(f'{GENLIBPATH} is missing: run `python -m boardlaw_amd.build`')
+        stamp = GENLIBPATH + '.torch'
+        if os.path.exists(stamp) and open(stamp).read().strip() != torch.__version__:
+            # the shim reads c10::GeneratorImpl / at::PhiloxCudaState by layout: never run it against another torch
+            raise NativeError(f'{GENLIBPATH} was built for torch {open(stamp).read().strip()}, this is {torch.__version__}: '
+                              'run `python -m boardlaw_amd.build`')
         L = ctypes.CDLL(GENLIBPATH)
         L.bl_torch_philox_state.restype, L.bl_torch_philox_state.argtypes = _i, [_vp, ctypes.c_uint64, ctypes.POINTER(ctypes.c_int64)]
         _genlib = L

@@ -227,9 +227,7 @@ def chunk_jobs(games, names, n_envs_per, chunks):
 def _chunk_job(worldfunc, agentfunc, names, played, n_envs_per):
     agents = {n: agentfunc(n) for n in names}
     device = 'cuda' if torch.cuda.is_available() else 'cpu'
-    evaluator = ChunkEvaluator(worldfunc, agents, None, n_envs_per=n_envs_per, device=device)
-    evaluator.tracker = Tracker(n_envs_per, played, names=names, device=device)      # games already on record are not replayed
-    evaluator.worlds = worldfunc(evaluator.tracker.n_envs).to(device)
+    evaluator = ChunkEvaluator(worldfunc, agents, played, n_envs_per=n_envs_per, device=device)     # games already on record are not replayed
     results = []
     while not evaluator.finished():
         results.extend(evaluator.step())
@@ -251,10 +249,10 @@ def _pool_worker(index, n_devices, inbox, outbox):
                 outbox.put((key, fn(*args), None))
         except BaseException as e:           # the parent re-raises
             import traceback
-            outbox.put((key, None, f'{type(e).__name__}: {e}\\n{traceback.format_exc()}'))
+            outbox.put((key, None, f'{type(e).__name__}: {e}\n{traceback.format_exc()}'))
 
 
-def run_jobs(jobs, n_workers=None, context='spawn'):
+def run_jobs(jobs, n_workers=None, context='spawn', poll_seconds=2.0):
     """jobs: {key: (picklable function, args)} -> yields (key, result) as they finish, from a pool of n_workers processes, one
     per GPU by default (worker n on GPU n % n_gpus).  n_workers == 0: everything in this process, in order (the reference's
     serial executor, rebar/parallel.py:15-27)."""
@@ -276,10 +274,21 @@ def run_jobs(jobs, n_workers=None, context='spawn'):
             inbox.put((key, fn, args))
         for _ in procs:
             inbox.put(None)
-        for _ in range(len(jobs)):
-            key, result, err = outbox.get()
+        import queue
+        outstanding = len(jobs)
+        while outstanding:
+            try:
+                key, result, err = outbox.get(timeout=poll_seconds)
+            except queue.Empty:
+                # a worker that died without posting (a crash inside the native library, an OOM kill) would leave this loop
+                # waiting for ever: the reference's ProcessPoolExecutor raises BrokenProcessPool there (rebar/parallel.py:28-57)
+                dead = [(i, p.exitcode) for i, p in enumerate(procs) if not p.is_alive() and p.exitcode not in (0, None)]
+                if dead or not any(p.is_alive() for p in procs):
+                    raise RuntimeError(f'arena worker(s) died with {outstanding} job(s) outstanding: (worker, exit code) {dead}')
+                continue
             if err is not None:
-                raise RuntimeError(f'arena job {key} failed in its worker:\\n{err}')
+                raise RuntimeError(f'arena job {key} failed in its worker:\n{err}')
+            outstanding -= 1
             yield key, result
     finally:
         for p in procs:

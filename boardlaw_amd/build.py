@@ -15,11 +15,12 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 UNITS = ('bl_kernels.hip', 'bl_expand.hip', 'bl_mlp.hip', 'bl_root.hip', 'bl_rand.hip')
 SOURCES = [os.path.join(HERE, 'csrc', f) for f in UNITS]
-HEADERS = [os.path.join(ROOT, 'include', 'boardlaw_amd.h'), os.path.join(HERE, 'csrc', 'bl_device.h')]
+HEADERS = [os.path.join(ROOT, 'include', 'boardlaw_amd.h')] + [os.path.join(HERE, 'csrc', h) for h in ('bl_device.h', 'bl_host.h')]
 OBJDIR = os.path.join(HERE, 'build')
 LIB = os.path.join(HERE, 'libboardlaw_amd.so')
 GEN_SRC = os.path.join(HERE, 'csrc', 'bl_torchgen.cpp')
 GEN_LIB = os.path.join(HERE, 'libbl_torchgen.so')
+GEN_STAMP = GEN_LIB + '.torch'      # the torch version the shim was compiled against: it reads torch C++ objects by layout
 
 # -ffp-contract=off: the search kernels must round like the reference's CPU path (no FMA); see DESIGN.md.
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-ffp-contract=off', '-fPIC', '-fno-gpu-flush-denormals-to-zero',
@@ -33,8 +34,17 @@ def _newer(target, deps):
     return any(os.path.getmtime(p) > built for p in deps)
 
 
+def _torchgen_stale():
+    """The shim touches c10::GeneratorImpl and at::PhiloxCudaState by layout, so a libbl_torchgen.so built against another torch
+    is stale whatever its mtime: the version it was built for is kept in a stamp file beside it."""
+    if _newer(GEN_LIB, [GEN_SRC]) or not os.path.exists(GEN_STAMP):
+        return True
+    import torch
+    return open(GEN_STAMP).read().strip() != torch.__version__
+
+
 def stale():
-    return _newer(LIB, SOURCES + HEADERS + [os.path.abspath(__file__)]) or _newer(GEN_LIB, [GEN_SRC])
+    return _newer(LIB, SOURCES + HEADERS + [os.path.abspath(__file__)]) or _torchgen_stale()
 
 
 def _hipcc():
@@ -45,7 +55,7 @@ def _hipcc():
 
 
 def build_torchgen(force=False, verbose=False):
-    if not force and not _newer(GEN_LIB, [GEN_SRC]):
+    if not force and not _torchgen_stale():
         return GEN_LIB
     import torch
     t = os.path.dirname(torch.__file__)
@@ -58,6 +68,8 @@ def build_torchgen(force=False, verbose=False):
         print(' '.join(cmd))
     subprocess.check_call(cmd)
     os.replace(GEN_LIB + '.tmp', GEN_LIB)
+    with open(GEN_STAMP, 'w') as f:
+        f.write(torch.__version__)
     return GEN_LIB
 
 

@@ -151,7 +151,13 @@ enum { EMPTY = 0, BLACK, WHITE, TOP, BOT, LEFT, RIGHT, MARK = 0xff };
 
 // One group steps one board held in LDS `cells` (A bytes).  Returns the winner's sign in `win` (0 none, +1 black
 // wins => rewards (+1,-1), -1 white wins => (-1,+1)).  Group-uniform control flow; `go` false groups idle.
-template <int G>
+// WAVE: the board belongs to ONE wave (G == 64) of a workgroup whose other waves are elsewhere -- the LDS round trips are ordered
+// by a wave-scope fence instead of the workgroup barrier (a wave's DS operations execute in order).
+template <bool WAVE> __device__ __forceinline__ void board_sync() {
+    if constexpr (WAVE) { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier(); }
+    else __syncthreads();
+}
+template <int G, bool WAVE = false>
 __device__ __forceinline__ int hex_step_group(uint8_t* cells, int S, int seat, int action, bool go, int gl) {
     const int A = S * S;
     const float invS = 1.0f / (float)S;
@@ -180,7 +186,7 @@ __device__ __forceinline__ int hex_step_group(uint8_t* cells, int S, int seat, i
     label = __shfl(label, 0, G); win = __shfl(win, 0, G);
     plain = (uint8_t)__shfl((int)plain, 0, G);
     const bool flooding = go && label >= TOP;
-    __syncthreads();
+    board_sync<WAVE>();
     // Relabel the 6-connected component of `plain` cells containing the start cell (== the BFS of cuda.cu:18-74):
     // sweep until no plain cell touches a MARKed one.
     while (true) {
@@ -197,11 +203,11 @@ __device__ __forceinline__ int hex_step_group(uint8_t* cells, int S, int seat, i
                 if (hit) { cells[a] = MARK; changed = true; }
             }
         }
-        __syncthreads();
+        board_sync<WAVE>();
         if (!__any(changed)) break;
     }
     if (flooding) for (int a = gl; a < A; a += G) if (cells[a] == MARK) cells[a] = (uint8_t)label;
-    __syncthreads();
+    board_sync<WAVE>();
     return win;
 }
 

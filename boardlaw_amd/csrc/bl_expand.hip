@@ -462,6 +462,377 @@ __global__ void __launch_bounds__(BL_WAVE * NW, (RMAX <= 3 ? 8 : 4)) sim_expand2
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// Round 4: NE envs per workgroup, and the waves of an env that has finished its descent help the envs still going.
+//
+// tools/deep_only_probe.py (profiles/r04_deep_only.txt) launches the kernel above on subsets of a search's envs: at simulation 63
+// of the bench workload the ONE deepest env (24 levels) alone takes 50 us of the whole launch's 67 us (eager), the 1024 deepest
+// alone 50 us, everything BUT the 1024 deepest 41 us -- a launch is its deepest descent's chain of batches (about 1.4 us per
+// level: a batch of two guessed levels is a memory trip for the rows, ~4.5 Newton iterations of ~730 cycles, the draw and the
+// hand-over) plus ~17 us of everybody else being in the way.  What shortens that chain is more guessed levels per batch; what
+// forbids it for every env is the chip's 8192 wave slots (four waves per env: 82 us).  So a workgroup here owns NE envs with two
+// waves each -- the same 8192 waves -- and a wave whose own env has finished (most descents are 2..6 levels) joins the env of
+// its workgroup that is still going: batches of 4, 6, 8 guessed levels for exactly the descents that are long, with waves
+// that would otherwise have left the chip.  Every level's result is still the exact evaluation of the node the descent is at
+// (evaluate_node is the batch evaluation of sim_expand2_kernel, instruction for instruction); which wave computes it changes
+// nothing.
+//
+// All waves of the workgroup run the batch loop in step (two barriers per batch).  Shared state in LDS: per env the slot
+// statistics a joining wave needs (st_*: q, n, info, uniform, fav of the env's 64 slots), the descent's state (es), the batch's
+// results (res).  Who works for whom is computed by every wave from that state with the same deterministic rule, so no
+// wave ever waits for an assignment: own waves keep positions 0 and 1; a free wave stays with the env it joined while that
+// goes on, else joins the env (at or beyond level `help_thresh`) with the fewest waves, the deepest first among equals.
+// ------------------------------------------------------------------------------------------------------------------
+template <int RMAX, bool FAST>
+__device__ __forceinline__ void evaluate_node(const Search& s, const long envbase, const int A, const int t, const int tinfo, const float rnd,
+                                              const float cpuct, const uint32_t qp, const int nn, int& action_o, int& child_o, int& sel_o) {
+    const int lane = threadIdx.x & 63;
+    const bool lowhalf = lane < 32;
+    const int el = lane & 31;
+    const int nk = tinfo & 0xffff, seat = (tinfo >> 16) & 1;
+    const int R = (nk + 31) >> 5;
+    const long row = (envbase + t) * A;
+    float top[RMAX], q[RMAX], term[RMAX], x[RMAX];
+    uint32_t cc[RMAX];
+    bool in[RMAX];
+#pragma unroll
+    for (int r = 0; r < RMAX; r++) {
+        const int e = 32 * r + el;
+        in[r] = (r < R) && (e < nk);
+        top[r] = 0.f; cc[r] = 0xffff0000u; q[r] = 0.f; term[r] = 0.f; x[r] = 0.f;
+        if (in[r]) { top[r] = s.cpi[row + e]; cc[r] = s.cca[row + e]; }
+    }
+    int Nloc = 0;
+#pragma unroll
+    for (int r = 0; r < RMAX; r++) {
+        if (r < R) {                                                  // wave-uniform: the bpermutes run with every lane enabled
+            const int c = (int)(int16_t)(cc[r] >> 16);
+            const bool ex = c >= 0;
+            const int src = ex ? c : 0;
+            const uint32_t q2 = (uint32_t)bperm_i(src & 63, (int)qp);
+            const int nv = bperm_i(src & 63, nn);
+            if (ex) q[r] = h2f((uint16_t)(seat ? (q2 >> 16) : q2));
+            if (lowhalf && in[r]) Nloc += ex ? nv : 1;
+        }
+    }
+    const int N = wave_sum_i32(Nloc) + (A - nk);                      // dropped actions are unexpanded: +1 each
+    const float lam = (cpuct * (float)N) / (float)(unsigned)(N + A);
+    float alpha = (nk < A) ? 1.e-4f : 0.f;                            // a dropped action's q + max(lambda pi, 1e-4)
+#pragma unroll
+    for (int r = 0; r < RMAX; r++) {
+        top[r] = lam * top[r];
+        if (in[r]) alpha = fmaxf(alpha, q[r] + fmaxf(top[r], 1.e-4f));
+    }
+    alpha = wave_max_f32(alpha);
+
+    // newton_search, cuda.cu:35-68; body per block count, quotients side by side (see sim_expand2_kernel)
+    float err = INFINITY;
+    const int last_e = nk - 1, rl = last_e >> 5;
+    const int laneS = (last_e & 31) + ((rl & 1) ? 32 : 0), laneG = (last_e & 31) + ((rl & 1) ? 0 : 32);
+    auto newton = [&](auto rr_c) __attribute__((always_inline)) {
+        constexpr int RR = decltype(rr_c)::value;
+        for (int it = 0; it < 101 && nk > 0; it++) {
+            float num[RR], den[RR], quo[RR];
+#pragma unroll
+            for (int r = 0; r < RR; r++) {
+                const bool isS = lowhalf != ((r & 1) != 0);
+                const float bot = alpha - q[r];
+                num[r] = isS ? top[r] : -top[r];
+                den[r] = isS ? bot : bot * bot;
+            }
+            ieee_div_n<RR>(num, den, quo);
+#pragma unroll
+            for (int r = 0; r < RR; r++) term[r] = quo[r];
+#pragma unroll
+            for (int r = 0; r < RR; r++) {
+                x[r] = term[r];
+                if (r == 0) { if (el == 0) x[0] = 0.f + x[0]; }          // the sums start from 0.f (cuda.cu:44): (+0) + (-0) = +0
+                else fold_carry<FAST>(x[r], x[r - 1 < 0 ? 0 : r - 1], term[r]);
+                fold_block<FAST>(x[r], term[r], r + 1 < RR ? 32 : nk - 32 * r);
+            }
+            const float Ssum = readlane_f(x[RR - 1], laneS), gsum_ = readlane_f(x[RR - 1], laneG);      // rl == RR - 1
+            if (it == 100) break;      // alpha moved after the 100th fold (cuda.cu:48-65): this pass only refreshed the terms
+            const float ne = Ssum - 1.f;
+            if ((ne < 1e-3f) || (err == ne)) break;
+            alpha -= ne / gsum_; err = ne;
+        }
+    };
+    static_assert(RMAX <= 6, "evaluate_node: up to 192 actions");
+    if (R <= 1) newton(std::integral_constant<int, 1>{});
+    else if (R == 2) newton(std::integral_constant<int, RMAX >= 2 ? 2 : 1>{});
+    else if (R == 3) newton(std::integral_constant<int, RMAX >= 3 ? 3 : 1>{});
+    else if (R == 4) newton(std::integral_constant<int, RMAX >= 4 ? 4 : 1>{});
+    else if (R == 5) newton(std::integral_constant<int, RMAX >= 5 ? 5 : 1>{});
+    else newton(std::integral_constant<int, RMAX >= 6 ? 6 : 1>{});
+
+    // the draw, cuda.cu:157-176
+    int sel_r = -1, sel_lane = 0, last_r = -1, last_lane = 0;
+#pragma unroll
+    for (int r = 0; r < RMAX; r++) {
+        if (r < R) {
+            const bool isS = lowhalf != ((r & 1) != 0);
+            const bool pos = in[r] && isS && term[r] > 0.f;
+            const unsigned long long hit = __builtin_amdgcn_ballot_w64(pos && x[r] >= rnd), anyp = __builtin_amdgcn_ballot_w64(pos);
+            if (sel_r < 0 && hit) { sel_r = r; sel_lane = __builtin_ctzll(hit); }
+            if (anyp) { last_r = r; last_lane = 63 - __builtin_clzll(anyp); }
+        }
+    }
+    if (sel_r < 0) { sel_r = last_r; sel_lane = last_lane; }
+    action_o = -1; child_o = -1; sel_o = 0;
+    if (sel_r >= 0) {
+        uint32_t ccs = 0;
+#pragma unroll
+        for (int r = 0; r < RMAX; r++) if (r == sel_r) ccs = (uint32_t)__builtin_amdgcn_readlane((int)cc[r], sel_lane);
+        action_o = (int)(ccs & 0xffffu);
+        sel_o = 32 * sel_r + (sel_lane & 31);
+        child_o = __builtin_amdgcn_readfirstlane((int)(int16_t)(ccs >> 16));
+    }
+}
+
+// es[e][...]: the descent of env e of the workgroup
+enum { ES_T = 0, ES_TINFO, ES_NLEV, ES_GOING, ES_PARENT, ES_ACTION, ES_SEL, ES_B, ES_CPUCT, ES_WORDS = 12 };
+
+template <int RMAX, bool FAST, int NE>
+__global__ void __launch_bounds__(BL_WAVE * 2 * NE, (RMAX <= 3 ? 8 : 4)) sim_expand4_kernel(Search s, int sim, const uint16_t* rands, int16_t* leaves_out,
+                                                                                        void* obs_out, uint8_t* valid_out, int32_t* leaf_seats_out,
+                                                                                        int deep_thresh, int help_thresh) {
+    constexpr int W = 2 * NE;                       // waves of the workgroup = the most positions a batch can have
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    __shared__ int st_qp[NE][64], st_nn[NE][64], st_info[NE][64], st_rd[NE][64], st_fav[NE][64];
+    __shared__ __attribute__((aligned(16))) int es[NE][ES_WORDS];
+    __shared__ __attribute__((aligned(16))) int res[NE][W][4];
+    const int S = s.S, A = S * S, T = s.T;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int nact = active_envs(s);
+
+    // ---- prologue: wave w loads the slot statistics of env w / 2 (lane t <-> slot t) and normalises q (transition_q,
+    // cuda.cu:101-105, both seats, once per launch); the even wave publishes them and the descent's start
+    uint32_t qp; int nn, info, rd, fav;
+    int cur = wave >> 1;                                               // the env whose statistics this wave's registers hold
+    {
+        // env e of workgroup g: launch slot g + e * gridDim.x -- with gridDim.x a multiple of 8 all NE envs of a workgroup are
+        // = g (mod 8), the XCD the workgroup runs on (bl_mlp.hip forms its row tiles by env mod 8)
+        const int slot = blockIdx.x + cur * gridDim.x;
+        int b = slot < s.B ? (s.order ? s.order[slot] : slot) : s.B;
+        if (b >= nact) b = -1;
+        b = __builtin_amdgcn_readfirstlane(b);
+        const long envbase = (long)(b < 0 ? 0 : b) * T;
+        uint32_t wp = 0; nn = 0; info = 0; rd = 0; fav = -1;
+        if (b >= 0 && lane < T) {
+            wp = *(const uint32_t*)(s.w + (envbase + lane) * 2);
+            nn = s.n[envbase + lane];
+            info = (int)(uint16_t)s.nk[envbase + lane] | ((s.seats[envbase + lane] & 1) << 16) | ((s.terminal[envbase + lane] ? 1 : 0) << 17);
+            rd = rands[envbase + lane];
+            fav = s.fav[envbase + lane];
+        }
+        float lo, hi;
+        load_qrange(s.qrange + (long)BL_QWORDS * sim, lo, hi);
+        const float rden = hi - lo + 1.e-4f;
+        const float den = (float)nn + 1.e-4f;
+        const float q0 = h2f((uint16_t)wp) / den, q1 = h2f((uint16_t)(wp >> 16)) / den;
+        qp = (uint32_t)f2h((q0 - lo) / rden) | ((uint32_t)f2h((q1 - lo) / rden) << 16);
+        if (!(wave & 1)) {
+            st_qp[cur][lane] = (int)qp; st_nn[cur][lane] = nn; st_info[cur][lane] = info; st_rd[cur][lane] = rd; st_fav[cur][lane] = fav;
+            const int info0 = __builtin_amdgcn_readfirstlane(info);
+            if (lane == 0) {
+                es[cur][ES_T] = 0; es[cur][ES_TINFO] = info0; es[cur][ES_NLEV] = 0;
+                es[cur][ES_GOING] = (b >= 0 && !((info0 >> 17) & 1) && T > 0) ? 1 : 0;
+                es[cur][ES_PARENT] = 0; es[cur][ES_ACTION] = -1; es[cur][ES_SEL] = 0; es[cur][ES_B] = b;
+                es[cur][ES_CPUCT] = b >= 0 ? (int)s.c_puct[b] : 0;
+            }
+        }
+    }
+    __syncthreads();
+
+    // who works for whom, replicated in every wave: aenv[w] / apos[w] = env and batch position of wave w (-1: idle)
+    int aenv[W], apos[W];
+#pragma unroll
+    for (int w = 0; w < W; w++) { aenv[w] = w >> 1; apos[w] = w & 1; }
+
+    for (int batch = 0; batch <= T; batch++) {
+        // ---- the descents' state
+        int going[NE], nlev[NE], anygoing = 0;
+#pragma unroll
+        for (int e = 0; e < NE; e++) {
+            going[e] = __builtin_amdgcn_readfirstlane(es[e][ES_GOING]);
+            nlev[e] = __builtin_amdgcn_readfirstlane(es[e][ES_NLEV]);
+            anygoing |= going[e];
+        }
+        if (!anygoing) break;
+        // ---- assignment (the same computation in every wave)
+        int cnt[NE];
+#pragma unroll
+        for (int e = 0; e < NE; e++) cnt[e] = going[e] ? 2 : 0;
+#pragma unroll
+        for (int w = 0; w < W; w++) {
+            if (going[w >> 1]) { aenv[w] = w >> 1; apos[w] = w & 1; }
+            else {
+                bool keeps = false;
+#pragma unroll
+                for (int e = 0; e < NE; e++) if (aenv[w] == e && e != (w >> 1) && going[e]) keeps = true;
+                if (!keeps) aenv[w] = -1;
+            }
+        }
+#pragma unroll
+        for (int w = 0; w < W; w++) {
+            if (!going[w >> 1] && aenv[w] >= 0) {
+#pragma unroll
+                for (int e = 0; e < NE; e++) if (aenv[w] == e) cnt[e] = cnt[e] > apos[w] + 1 ? cnt[e] : apos[w] + 1;
+            }
+        }
+#pragma unroll
+        for (int w = 0; w < W; w++) {
+            if (!going[w >> 1] && aenv[w] < 0) {
+                int best = -1, bestcnt = 0, bestlev = 0;
+#pragma unroll
+                for (int e = 0; e < NE; e++) {
+                    if (going[e] && nlev[e] >= help_thresh && cnt[e] < W && (best < 0 || cnt[e] < bestcnt || (cnt[e] == bestcnt && nlev[e] > bestlev))) {
+                        best = e; bestcnt = cnt[e]; bestlev = nlev[e];
+                    }
+                }
+                if (best >= 0) {
+                    aenv[w] = best; apos[w] = bestcnt;
+#pragma unroll
+                    for (int e = 0; e < NE; e++) if (e == best) cnt[e]++;
+                }
+            }
+        }
+        int me = -1, mypos = 0, mycnt = 0;
+#pragma unroll
+        for (int w = 0; w < W; w++) if (wave == w) { me = aenv[w]; mypos = apos[w]; }
+#pragma unroll
+        for (int e = 0; e < NE; e++) if (me == e) mycnt = cnt[e];
+
+        int ra = -2, rc = -1, rs = 0;
+        int u[W], uinfo[W];
+        int t = -1, tinfo = 0, lev = 0, b = -1;
+        float cpuct = 0.f;
+        if (me >= 0) {
+            if (me != cur) {                                       // joining another env: its slot statistics
+                qp = (uint32_t)st_qp[me][lane]; nn = st_nn[me][lane]; info = st_info[me][lane]; rd = st_rd[me][lane]; fav = st_fav[me][lane];
+                cur = me;
+            }
+            t = __builtin_amdgcn_readfirstlane(es[me][ES_T]); tinfo = __builtin_amdgcn_readfirstlane(es[me][ES_TINFO]);
+            lev = __builtin_amdgcn_readfirstlane(es[me][ES_NLEV]); b = __builtin_amdgcn_readfirstlane(es[me][ES_B]);
+            cpuct = h2f((uint16_t)__builtin_amdgcn_readfirstlane(es[me][ES_CPUCT]));
+            // the nodes of this batch: the current one and its guessed continuation
+            u[0] = t; uinfo[0] = tinfo;
+#pragma unroll
+            for (int k = 1; k < W; k++) {
+                u[k] = -1; uinfo[k] = 0;
+                if (k < mycnt && lev >= deep_thresh && u[k - 1] != -1 && !((uinfo[k - 1] >> 17) & 1)) {
+                    u[k] = __builtin_amdgcn_readfirstlane(__builtin_amdgcn_readlane(fav, u[k - 1] & 63));
+                    if (u[k] != -1) uinfo[k] = __builtin_amdgcn_readfirstlane(__builtin_amdgcn_readlane(info, u[k] & 63));
+                }
+            }
+            int my = -1, myinfo = 0;
+#pragma unroll
+            for (int k = 0; k < W; k++) if (mypos == k) { my = u[k]; myinfo = uinfo[k]; }
+            if (my != -1 && !((myinfo >> 17) & 1)) {
+                const float rnd = h2f((uint16_t)__builtin_amdgcn_readfirstlane(__builtin_amdgcn_readlane(rd, my & 63)));
+                evaluate_node<RMAX, FAST>(s, (long)b * T, A, my, myinfo, rnd, cpuct, qp, nn, ra, rc, rs);
+            }
+            if (lane == 0) { res[me][mypos][0] = ra; res[me][mypos][1] = rc; res[me][mypos][2] = rs; }
+        }
+        __syncthreads();
+        // ---- follow the drawn edges through the batch (every wave of the env, the same scalar walk; position 0 publishes)
+        if (me >= 0) {
+            int16_t* path = s.path ? s.path + (long)b * (T + 2) : nullptr;
+            int parent = 0, action = -1, sel_e = 0;
+            bool live = true;
+#pragma unroll
+            for (int k = 0; k < W; k++) {
+                if (k < mycnt) {
+                    const int a_k = __builtin_amdgcn_readfirstlane(res[me][k][0]), c_k = __builtin_amdgcn_readfirstlane(res[me][k][1]);
+                    const int s_k = __builtin_amdgcn_readfirstlane(res[me][k][2]);
+                    const int node = u[k];
+                    if (path && mypos == 0 && lane == 0) path[1 + lev] = (int16_t)node;
+                    lev++;
+                    parent = node; sel_e = s_k;
+                    if (a_k < 0) { action = -1; live = false; break; }       // no action with positive probability: the reference would index [-1]
+                    action = a_k;
+                    {
+                        // node's most visited child once this descent is backed up: the drawn child gains a visit (n += 2)
+                        const int cnew = c_k == -1 ? sim : c_k;
+                        const int f_old = __builtin_amdgcn_readfirstlane(__builtin_amdgcn_readlane(fav, node & 63));
+                        bool upd = f_old == -1;
+                        if (!upd) upd = __builtin_amdgcn_readlane(nn, cnew & 63) + 2 >= __builtin_amdgcn_readlane(nn, f_old & 63);
+                        if (upd) {
+                            if (lane == (node & 63)) fav = cnew;
+                            if (mypos == 0 && lane == 0) st_fav[me][node & 63] = cnew;
+                        }
+                    }
+                    t = c_k;
+                    if (t == -1) break;
+                    tinfo = __builtin_amdgcn_readfirstlane(__builtin_amdgcn_readlane(info, t & 63));
+                    if ((tinfo >> 17) & 1) break;
+                    if (!(k + 1 < mycnt && u[k + 1 < W ? k + 1 : 0] == t)) break;      // the guess ends here: next batch starts at t
+                }
+            }
+            if (mypos == 0 && lane == 0) {
+                es[me][ES_T] = t; es[me][ES_TINFO] = tinfo; es[me][ES_NLEV] = lev;
+                es[me][ES_GOING] = (live && t != -1 && !((tinfo >> 17) & 1) && lev < T) ? 1 : 0;
+                es[me][ES_PARENT] = parent; es[me][ES_ACTION] = action; es[me][ES_SEL] = sel_e;
+            }
+        }
+        __syncthreads();
+    }
+    if (wave >= NE) return;
+
+    // ---- wave e < NE expands env e: leaves = children[envs, parents, actions]; leaves[leaves == -1] = sim (mcts/__init__.py:117-122)
+    const int e = wave;
+    const int b = __builtin_amdgcn_readfirstlane(es[e][ES_B]);
+    if (b < 0) return;
+    const long envbase = (long)b * T;
+    const int nlev = __builtin_amdgcn_readfirstlane(es[e][ES_NLEV]), parent = __builtin_amdgcn_readfirstlane(es[e][ES_PARENT]);
+    const int sel_e = __builtin_amdgcn_readfirstlane(es[e][ES_SEL]), nxt = __builtin_amdgcn_readfirstlane(es[e][ES_T]);
+    int action = __builtin_amdgcn_readfirstlane(es[e][ES_ACTION]);
+    if (action < 0) action = 0;
+    if (lane < T) s.fav[envbase + lane] = (int16_t)st_fav[e][lane];
+    int16_t* path = s.path ? s.path + (long)b * (T + 2) : nullptr;
+    uint8_t* cells = (uint8_t*)smem + (size_t)e * al16(A);
+    const int leaf = (nxt == -1) ? sim : nxt;
+    if (s.lazy) lazy_slot_reset(s, envbase, sim, A, nxt == -1, lane);
+    if (lane == 0) {
+        s.children[(envbase + parent) * A + action] = (int16_t)leaf;
+        s.parents[envbase + leaf] = (int16_t)parent;
+        s.relation[envbase + leaf] = (int16_t)action;
+        if (nxt == -1 && nlev > 0) ((uint16_t*)(s.cca + (envbase + parent) * A + sel_e))[1] = (uint16_t)leaf;   // the compacted row's child field
+    }
+    const int seat = s.seats[envbase + parent];
+    const uint8_t* src = s.boards + (envbase + parent) * A;
+    for (int a = lane; a < A; a += 64) cells[a] = src[a];
+    board_sync<true>();
+    const int win = hex_step_group<64, true>(cells, S, seat, action, true, lane);
+    // Hex.step tail, hex/__init__.py:183-190
+    const bool term = win != 0;
+    const int new_seat = term ? 0 : 1 - seat;
+    uint8_t* dst = s.boards + (envbase + leaf) * A;
+    const float invS = 1.0f / (float)S;
+    const bool flip = new_seat == 1;
+    for (int a = lane; a < A; a += 64) dst[a] = term ? (uint8_t)0 : cells[a];
+    for (int a = lane; a < A; a += 64) {
+        const int i = (int)(((float)a + 0.5f) * invS), j = a - i * S;
+        const int color = term ? 2 : color_of(cells[flip ? j * S + i : a]);
+        const int ch = color < 2 ? (flip ? 1 - color : color) : 2;
+        if (s.obs_f16) ((uint32_t*)obs_out)[(long)b * A + a] = ch == 0 ? 0x00003c00u : (ch == 1 ? 0x3c000000u : 0u);   // f16 1.0 = 0x3c00
+        else ((float2*)obs_out)[(long)b * A + a] = make_float2(ch == 0 ? 1.f : 0.f, ch == 1 ? 1.f : 0.f);
+        valid_out[(long)b * A + a] = color == 2;
+    }
+    if (lane == 0) {
+        s.seats[envbase + leaf] = new_seat;
+        s.terminal[envbase + leaf] = term;
+        s.rewards[(envbase + leaf) * 2 + 0] = f2h((float)win);
+        s.rewards[(envbase + leaf) * 2 + 1] = f2h((float)(-win));
+        leaves_out[b] = (int16_t)leaf;
+        leaf_seats_out[b] = new_seat;
+        if (path) {
+            path[1 + nlev] = (int16_t)leaf;
+            path[0] = (int16_t)(nlev + 1);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 // Two nodes per wave.  While every env still descends, the kernel is bound by VALU issue (4.3 k VALU instructions per env,
 // 8 waves per SIMD), and more than half of those are the folds' v_add_f32_dpp -- whose count depends on the chain length, not
 // on how many chains a step advances.  Here ONE wave per env evaluates the current node in lanes 0..31 and its guessed
@@ -798,9 +1169,22 @@ using namespace bl;
 // the general kernel of bl_kernels.hip).  waves: 1, or 4 = speculative batches for envs whose last descent had at least
 // `deep_thresh` nodes (needs s.fav).
 int bl_expand2_launch(const Search& ss, int sim, const void* rands, int16_t* leaves, void* obs, uint8_t* valid, int32_t* leaf_seats,
-                      unsigned long long* counters, int fast, int waves, int deep_thresh, hipStream_t stream) {
+                      unsigned long long* counters, int fast, int waves, int deep_thresh, int envs, int help_thresh, hipStream_t stream) {
     const int A = ss.S * ss.S, T = ss.T;
     if (!ss.cpi || !ss.cca || !ss.nk || A > 384 || T > 256) return BL_ETOOBIG;
+    if ((envs == 2 || envs == 4) && ss.fav && A <= 192 && T <= 64 && !counters) {
+        // envs per workgroup, two waves each, finished envs' waves help the ones still going (sim_expand4_kernel)
+        const dim3 grid4((ss.B + envs - 1) / envs), block4(64 * 2 * envs);
+        const size_t lds4 = (size_t)al16(A) * envs;
+#define BLX4(R_, NE_) { if (fast) hipLaunchKernelGGL((sim_expand4_kernel<R_, true, NE_>), grid4, block4, lds4, stream, ss, sim, (const uint16_t*)rands, leaves, obs, valid, leaf_seats, deep_thresh, help_thresh); \
+                        else hipLaunchKernelGGL((sim_expand4_kernel<R_, false, NE_>), grid4, block4, lds4, stream, ss, sim, (const uint16_t*)rands, leaves, obs, valid, leaf_seats, deep_thresh, help_thresh); }
+#define BLX4E(R_) { if (envs == 2) BLX4(R_, 2) else BLX4(R_, 4) }
+        const int need4 = (A + 31) / 32;
+        if (need4 <= 1) BLX4E(1) else if (need4 <= 2) BLX4E(2) else if (need4 <= 3) BLX4E(3) else BLX4E(6)
+#undef BLX4E
+#undef BLX4
+        return hipGetLastError() == hipSuccess ? BL_OK : BL_ELAUNCH;
+    }
     if (waves == 21 && ss.fav && A <= 96 && T <= 64 && !counters) {
         // two nodes per wave (sim_expand3_kernel)
         const dim3 grid3(ss.B), block3(64);

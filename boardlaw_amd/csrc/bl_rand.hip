@@ -14,6 +14,7 @@
 #include <stdint.h>
 #include "../../include/boardlaw_amd.h"
 #include "bl_device.h"
+#include "bl_host.h"
 
 namespace bl {
 
@@ -109,6 +110,9 @@ extern "C" int bl_rand_block(void* out, int n_calls, long numel, long threads, i
     if (only_slots_upto_call < 0 || (only_slots_upto_call > 0 && numel % only_slots_upto_call != 0)) return BL_EINVAL;
     if (only_slots_upto_call > 0 && loops == 1 && threads >= numel && only_slots_upto_call <= 1024 && n_calls <= 65535) {
         const int T = only_slots_upto_call, B = (int)(numel / T);
+        // 64 x (T + 2) f16 of LDS: above 64 KiB (T >= 511) the kernel's dynamic-LDS limit has to be raised first
+        static size_t raised[64] = {};
+        if (!bl_raise_lds_limit((const void*)bl::rand_block_slots_kernel, (size_t)64 * (T + 2) * 2, raised)) return BL_ELAUNCH;
         hipLaunchKernelGGL(bl::rand_block_slots_kernel, dim3((unsigned)((B + 63) / 64), (unsigned)n_calls), dim3(256), (size_t)64 * (T + 2) * 2,
                            (hipStream_t)stream, (uint16_t*)out, n_calls, B, T, seed_or_ptr, offset_or_ptr, offset_intragraph, captured);
         return hipGetLastError() == hipSuccess ? BL_OK : BL_ELAUNCH;

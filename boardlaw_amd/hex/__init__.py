@@ -121,17 +121,24 @@ class Lazy(Solitaire):
     """Opponent plays the first available cell (hex/__init__.py:257-266)."""
 
     @classmethod
+    def _reply(cls, worlds):
+        return worlds.valid.int().argmax(-1)        # lowest index with valid == True
+
+    @classmethod
     def _play(cls, worlds):
-        first = worlds.valid.int().argmax(-1)       # lowest index with valid == True
-        return Hex.step(worlds, first)
+        return Hex.step(worlds, cls._reply(worlds))
 
 
 class Random(Solitaire):
     """Opponent plays a uniformly random available cell (hex/__init__.py:268-274)."""
 
     @classmethod
+    def _reply(cls, worlds):
+        return torch.distributions.Categorical(probs=worlds.valid.float()).sample()
+
+    @classmethod
     def _play(cls, worlds):
-        return Hex.step(worlds, torch.distributions.Categorical(probs=worlds.valid.float()).sample())
+        return Hex.step(worlds, cls._reply(worlds))
 
 
 def board_actions(s):

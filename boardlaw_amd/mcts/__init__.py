@@ -186,6 +186,9 @@ class MCTS:
         self.fused = (isinstance(world, hexmod.Hex) and world.n_seats == 2) if fused is None else fused
         if self.fused and not isinstance(world, hexmod.Hex):
             raise ValueError('The fused path is Hex-only')
+        if n_active is not None and not self.fused:
+            # the generic path searches every row it is given: padded rows would be searched and feed the batch-global q range
+            raise ValueError('n_active (masked captured moves) needs the fused Hex path; call the agent with pad=False for other worlds')
         B, T, A, S, dev = self.n_envs, n_nodes, self.n_actions, self.n_seats, self.device
         self._envs = None
         self.sim = 0
@@ -476,12 +479,23 @@ class MCTSAgent:
         self.pad = pad
         self._graphs = {}           # insertion-ordered: oldest use first
 
-    def _capacity(self, n):
+    # A padded replay equals the eager call on the same envs because torch's Dirichlet / uniform kernels give element i the same
+    # number whatever the tensor's size -- true while one launch covers the tensor with one element per thread, i.e. up to
+    # CUs x 2048 threads (torch_rand_geometry: `loops` == 1).  Above that the grid-stride loop maps counters to elements by the
+    # grid size, so padding is switched off there (the move is captured for exactly n envs).
+    def _pad_keeps_the_stream(self, cap, world):
+        props = torch.cuda.get_device_properties(world.device)
+        threads = props.multi_processor_count * (props.max_threads_per_multi_processor // 256) * 256
+        return cap * int(np.prod(world.action_space)) <= threads
+
+    def _capacity(self, n, world=None):
         if not self.pad:
             return n
         cap = self.MIN_CAPACITY
         while cap < n:
             cap *= 2
+        if world is not None and not (cap == n or self._pad_keeps_the_stream(cap, world)):
+            return n
         return cap
 
     def _kwargs_key(self):
@@ -523,9 +537,12 @@ class MCTSAgent:
     def __call__(self, world, value=True, eval=False, **kwargs):
         if not self.graph or kwargs or world.device.type != 'cuda':
             return self._move(world, eval, kwargs)
-        cap = self._capacity(world.n_envs)
+        from .. import hex as hexmod
+        fused = self.kwargs.get('fused')
+        fused = (isinstance(world, hexmod.Hex) and world.n_seats == 2) if fused is None else fused
+        cap = self._capacity(world.n_envs, world) if fused else world.n_envs     # n_active exists on the fused path only
         key = (type(world), cap, world.boardsize, bool(eval), world.device)
-        return self._graphed(key, lambda: _GraphedMove(self, world, eval, capacity=cap))(world)
+        return self._graphed(key, lambda: _GraphedMove(self, world, eval, capacity=cap if (self.pad and fused) else None))(world)
 
     @profiling.roctx
     def play(self, world, eval=False):

@@ -50,6 +50,11 @@ typedef struct {
                           if the simulation creates no node also logits[b,sim,:] = NaN and the root board in boards[b,sim]).  After
                           all T-1 simulations every array equals the eager reset's; before that, slots > sim are undefined: for
                           callers that always run a whole search (MCTSAgent) */
+    int expand_envs;   /* envs per workgroup in bl_sim_expand (T <= 64): 0 = default; 1 = one (two or four waves of its own per env);
+                          2 / 4 = that many, two waves each, and the waves of an env whose descent has ended join the envs of their
+                          workgroup that still go (batches of 4..8 guessed levels for exactly the long descents).  Ignored when
+                          expand_waves is set */
+    int expand_help;   /* with expand_envs 2 / 4: free waves join an env only from this descent level on (default 0) */
 } bl_tune_t;
 
 int bl_abi_version(void);

@@ -455,7 +455,7 @@ def gen_arena(hex_, out):
     common, neural = import_reference_arena()
     import pandas as pd
     res = {}
-    for S, n_envs in ((5, 64), (7, 2048), (9, 2048), (11, 2048)):
+    for S, n_envs in ((5, 64), (7, 2048), (9, 2048), (11, 2048), (3, 2048)):     # 3x3: the small end of config 5's sweep (round 4)
         start = premixed_worlds(hex_, n_envs, S, S * S // 3, 500 + S)
         res[f'S{S}_board'] = np_(start.board); res[f'S{S}_seats'] = np_(start.seats)
         agents = {'front': EdgeAgent(False, 1), 'back': EdgeAgent(True, 0)}
@@ -490,6 +490,48 @@ def gen_arena(hex_, out):
         res[f'chunk{S}_final_wins'] = np_(ev.stats.wins); res[f'chunk{S}_final_moves'] = np_(ev.stats.moves)
         print('chunk', S, len(picks), 'steps', [(r.names, r.wins, r.moves) for r in results])
     np.savez_compressed(os.path.join(out, 'arena.npz'), **res)
+
+
+# --------------------------------------------------------------------------------------------------------------
+# 10. One-player Hex (boardlaw/hex/__init__.py:224-271): the reference's Lazy and Random worlds stepped with seeded player
+#     moves.  Every Hex.step the reference makes is recorded in call order -- the player's move, then the opponent's replies on
+#     the sub-batch that still owes one -- so a replay needs no random stream of its own: Random's opponent draws are data.
+# --------------------------------------------------------------------------------------------------------------
+def gen_solitaire(hex_, out):
+    res = {}
+    for kind in ('Lazy', 'Random'):
+        cls = getattr(hex_, kind)
+        for S in (3, 5, 7):
+            torch.manual_seed(700 + S)
+            B = 32
+            worlds = cls.initial(B, S, device='cpu')
+            calls = []                      # (outer step, sub-batch size, actions) of every Hex.step
+            orig = hex_.Hex.step
+            step_no = [0]
+
+            def recording(self, actions, _orig=orig):
+                calls.append((step_no[0], int(actions.shape[0]), np_(actions.long())))
+                return _orig(self, actions)
+            rec = {k: [] for k in ('board', 'seats', 'actions', 'new_board', 'new_seats', 'rewards', 'terminal', 'obs', 'valid')}
+            hex_.Hex.step = recording
+            try:
+                for t in range(2 * S * S):
+                    step_no[0] = t
+                    actions = torch.distributions.Categorical(probs=worlds.valid.float()).sample()
+                    rec['board'].append(np_(worlds.board)); rec['seats'].append(np_(worlds.seats)); rec['actions'].append(np_(actions))
+                    rec['obs'].append(np_(worlds.obs).astype(np.uint8)); rec['valid'].append(np_(worlds.valid))
+                    worlds, trans = worlds.step(actions)
+                    assert trans.rewards.shape == (B, 1) and worlds.n_seats == 1
+                    rec['new_board'].append(np_(worlds.board)); rec['new_seats'].append(np_(worlds.seats))
+                    rec['rewards'].append(np_(trans.rewards)); rec['terminal'].append(np_(trans.terminal))
+            finally:
+                hex_.Hex.step = orig
+            for k, v in rec.items():
+                res[f'{kind}{S}_{k}'] = np.stack(v)
+            res[f'{kind}{S}_call_step'] = np.array([c[0] for c in calls]); res[f'{kind}{S}_call_size'] = np.array([c[1] for c in calls])
+            res[f'{kind}{S}_call_actions'] = np.concatenate([c[2] for c in calls])
+            print('solitaire', kind, S, len(calls), 'Hex.step calls in', 2 * S * S, 'steps; games ended', int(np.stack(rec['terminal']).sum()))
+    np.savez_compressed(os.path.join(out, 'solitaire.npz'), **res)
 
 
 # --------------------------------------------------------------------------------------------------------------
@@ -585,6 +627,7 @@ if __name__ == '__main__':
     if want('learner'): gen_learner(mcts_mod, hex_, networks, out)
     if want('arena'): gen_arena(hex_, out)
     if want('rollout'): gen_rollout(hex_, out)
+    if want('solitaire'): gen_solitaire(hex_, out)
 
 
 # tests/golden/learning.npz: produced by calling the reference's boardlaw.learning.reward_to_go / present_value on seeded

@@ -94,7 +94,7 @@ def _check_chunk_evaluator(g, S, kind, device):
     assert np.array_equal(ev.wins.cpu().numpy(), g[f'chunk{S}_final_wins']) and np.array_equal(ev.moves.cpu().numpy(), g[f'chunk{S}_final_moves'])
 
 
-@pytest.mark.parametrize('S', [5, 7])
+@pytest.mark.parametrize('S', [3, 5, 7])
 def test_arena_evaluate_matches_reference_cpu(oracle, S):
     _check_evaluate(_gold('arena.npz'), S, oracle_hex(oracle), 'cpu')
 
@@ -105,7 +105,7 @@ def test_chunk_evaluator_matches_reference_cpu(oracle, S):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('S', [5, 7, 9, 11])
+@pytest.mark.parametrize('S', [3, 5, 7, 9, 11])
 def test_arena_evaluate_matches_reference_gpu(S):
     """config 5's shape -- 2048 envs per board size through arena.evaluate's masked variable-size calls -- on the product's Hex."""
     from boardlaw_amd.hex import Hex
@@ -117,6 +117,62 @@ def test_arena_evaluate_matches_reference_gpu(S):
 def test_chunk_evaluator_matches_reference_gpu(S):
     from boardlaw_amd.hex import Hex
     _check_chunk_evaluator(_gold('arena.npz'), S, Hex, 'cuda')
+
+
+# ------------------------------------------------------------------------------------------------ one-player Hex (round 4)
+def _check_solitaire(g, kind_name, S, base, device):
+    """solitaire.npz: the reference's hex.Lazy / hex.Random (hex/__init__.py:224-271) stepped with seeded player moves; every
+    Hex.step the reference made is on record in call order (the player's move on all envs, then the opponent's replies on the
+    sub-batch that owes one), so Random's opponent is replayed from data and Lazy's own choice is checked against it."""
+    from boardlaw_amd import hex
+    product = getattr(hex, kind_name)
+    step_of, size_of = g[f'{kind_name}{S}_call_step'], g[f'{kind_name}{S}_call_size']
+    offsets = np.concatenate([[0], np.cumsum(size_of)])
+    flat = g[f'{kind_name}{S}_call_actions']
+    pending = []
+
+    class Replayed(product, base):             # Solitaire.step -> base.step (the oracle's dynamics on the CPU, the product's on the GPU)
+        @classmethod
+        def _play(cls, worlds):
+            want = torch.from_numpy(pending.pop(0)).to(worlds.device)
+            assert want.shape[0] == worlds.n_envs, 'the opponent answers a different sub-batch than in the reference'
+            if kind_name == 'Lazy':
+                assert torch.equal(product._reply(worlds), want), 'Lazy picks another cell than the reference'
+            return base.step(worlds, want)
+
+    B = g[f'{kind_name}{S}_board'].shape[1]
+    worlds = Replayed(board=torch.from_numpy(g[f'{kind_name}{S}_board'][0]).to(device), seats=torch.from_numpy(g[f'{kind_name}{S}_seats'][0]).to(device))
+    assert worlds.n_seats == 1
+    for t in range(g[f'{kind_name}{S}_board'].shape[0]):
+        assert np.array_equal(worlds.board.cpu().numpy(), g[f'{kind_name}{S}_board'][t]) and np.array_equal(worlds.seats.cpu().numpy(), g[f'{kind_name}{S}_seats'][t])
+        assert np.array_equal(worlds.obs.cpu().numpy().astype(np.uint8), g[f'{kind_name}{S}_obs'][t])
+        assert np.array_equal(worlds.valid.cpu().numpy().astype(np.uint8), g[f'{kind_name}{S}_valid'][t])
+        calls = np.nonzero(step_of == t)[0]
+        assert size_of[calls[0]] == B
+        player = flat[offsets[calls[0]]:offsets[calls[0] + 1]]
+        assert np.array_equal(player, g[f'{kind_name}{S}_actions'][t])
+        pending[:] = [flat[offsets[c]:offsets[c + 1]] for c in calls[1:]]
+        worlds, trans = worlds.step(torch.from_numpy(player).to(device))
+        assert not pending, 'the reference made more opponent replies in this step'
+        assert type(worlds) is Replayed and trans.rewards.shape == (B, 1)
+        assert np.array_equal(worlds.board.cpu().numpy(), g[f'{kind_name}{S}_new_board'][t]), (kind_name, S, t)
+        assert np.array_equal(worlds.seats.cpu().numpy(), g[f'{kind_name}{S}_new_seats'][t])
+        assert np.array_equal(trans.rewards.cpu().numpy(), g[f'{kind_name}{S}_rewards'][t])
+        assert np.array_equal(trans.terminal.cpu().numpy().astype(np.uint8), g[f'{kind_name}{S}_terminal'][t])
+
+
+@pytest.mark.parametrize('kind_name', ['Lazy', 'Random'])
+@pytest.mark.parametrize('S', [3, 5, 7])
+def test_one_player_hex_matches_reference_cpu(oracle, kind_name, S):
+    _check_solitaire(_gold('solitaire.npz'), kind_name, S, oracle_hex(oracle), 'cpu')
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('kind_name', ['Lazy', 'Random'])
+@pytest.mark.parametrize('S', [3, 5, 7])
+def test_one_player_hex_matches_reference_gpu(kind_name, S):
+    from boardlaw_amd.hex import Hex
+    _check_solitaire(_gold('solitaire.npz'), kind_name, S, Hex, 'cuda')
 
 
 # -------------------------------------------------------------------------------------------------------------- learner

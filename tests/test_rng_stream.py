@@ -137,11 +137,12 @@ def test_seeded_agent_under_move_rng_is_the_torch_rng_agent(S, B, T, width, dept
         assert torch.equal(ba, bb) and torch.equal(sa, sb)
 
 
-def test_rand_block_for_descents_writes_the_slots_a_descent_can_read():
+@pytest.mark.parametrize('B,T', [(777, 64), (130, 512), (70, 1024)])
+def test_rand_block_for_descents_writes_the_slots_a_descent_can_read(B, T):
     """slots_upto_call (what mcts() asks for on the fused path): call c's tensor carries the reference's uniforms in the slots
-    t <= c -- every node that exists at descend #c+1 -- and the generator still ends where T-1 rand_like calls end."""
+    t <= c -- every node that exists at descend #c+1 -- and the generator still ends where T-1 rand_like calls end.
+    T = 512 / 1024: the tile is 64 x (T + 2) f16 of LDS, above the 64 KiB a kernel gets without asking (round-3 advisor finding)."""
     from boardlaw_amd.mcts import MoveRng
-    B, T = 777, 64
     like = torch.empty((B, T), dtype=torch.half, device=DEV)
     torch.manual_seed(5)
     want = torch.stack([torch.rand_like(like) for _ in range(T - 1)])

@@ -448,6 +448,9 @@ def test_run_jobs_pool_and_serial():
         assert dict(arena.run_jobs(jobs, n_workers=2)) == {k: k * k for k in range(7)}
         with pytest.raises(RuntimeError, match='failed in its worker'):
             dict(arena.run_jobs({0: (pool_helpers.square, ('x', 'y'))}, n_workers=1))
+        # a worker that dies without posting must not leave the parent waiting for ever (round-3 advisor finding)
+        with pytest.raises(RuntimeError, match='died with 1 job'):
+            dict(arena.run_jobs({0: (pool_helpers.die, (3,))}, n_workers=1, poll_seconds=0.2))
     finally:
         os.environ['PYTHONPATH'] = env
 
