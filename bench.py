@@ -202,6 +202,7 @@ def main():
     ap.add_argument('--timed-only', action='store_true', help='for profilers: only capture, warm-up and the timed moves; prints a reduced line')
     ap.add_argument('--no-reference-rng', action='store_true', help='skip the second timed region (torch rand_like per simulation)')
     ap.add_argument('--no-two-actors', action='store_true', help='skip the two-actors-per-GPU region')
+    ap.add_argument('--no-fold-safe', action='store_true', help='skip the timed region with the ISA-padded fold (value_fold_safe)')
     ap.add_argument('--no-soak', action='store_true', help='skip the 200 extra moves behind value_after_self_play_drift')
     ap.add_argument('--eager', action='store_true', help='launch kernel by kernel instead of replaying a HIP graph per move')
     args = ap.parse_args()
@@ -292,6 +293,27 @@ def main():
         barrier()
         value_torch_rng = args.envs * NODES * args.steps / (time.perf_counter() - t1)
         del ref_agent, w2
+
+    value_fold_safe = None
+    if world == 1 and not args.eager and not args.no_fold_safe:
+        # the same moves with the ISA-padded fold (two wait states between a VALU write and the DPP read of it; the headline runs
+        # the one-wait-state fold only because bl_selftest() verified it on THIS device -- a device that fails the self-test gets
+        # this rate).  BL_FOLD_SAFE is read by the host layer when a search is built, i.e. at this agent's capture.
+        os.environ['BL_FOLD_SAFE'] = '1'
+        try:
+            safe_agent = MCTSAgent(agent.network, n_nodes=NODES, graph=True, rng=MoveRng())
+            w5 = worlds
+            for _ in range(1 + min(args.warmup, 2)):
+                w5 = safe_agent.play(w5)[1]
+            barrier()
+            t4 = time.perf_counter()
+            for _ in range(args.steps):
+                w5 = safe_agent.play(w5)[1]
+            barrier()
+            value_fold_safe = args.envs * NODES * args.steps / (time.perf_counter() - t4)
+            del safe_agent, w5
+        finally:
+            del os.environ['BL_FOLD_SAFE']
 
     two_actors = None
     if world == 1 and not args.eager and not args.no_two_actors and default_shape:
@@ -393,9 +415,19 @@ def main():
                        'network': ('nn.Module under fp16 autocast' if args.plain_network else 'fp16 inference plan, torch GEMMs (bit-identical to autocast)'
                                    if args.torch_gemms
                                    else 'a launch per Linear, bl_mlp_layers_f16 (autocast rounding points), + bl_sim_finish' if not agent.network.prefers_fused(args.envs)
-                                   else 'fused MFMA kernel bl_sim_infer_finish (autocast rounding points; <= 1 f16 ulp vs autocast)') + '; root evaluation fp32',
+                                   else 'fused MFMA kernel bl_sim_infer_finish (autocast rounding points, another GEMM summation order: every pre-head output within '
+                                        '3 f16 ulp of the activation scale + 1 % of autocast\'s, >= 99 % within 1 ulp -- tests/test_gpu_parity.py::test_fused_mlp_matches_autocast)')
+                                   + '; root evaluation fp32',
                        'rng': 'MoveRng: stream-identical to the reference protocol (torch generator; Dirichlet and Categorical are torch\'s own calls; the T-1 rand_like (B,T) f16 draws of a move come from ONE launch, bl_rand_block, that evaluates the Philox counters those calls would use and advances the generator by what they would consume -- tests/test_rng_stream.py)',
                        'rng_stream_identical_to_reference_protocol': True,
+                       'seeded_run_vs_reference': 'the RANDOM DRAWS are the reference protocol\'s bit for bit and the tree arithmetic is the reference CPU path\'s bit for bit GIVEN '
+                                                  'the leaf evaluations; the leaf evaluations are f16 MFMA GEMMs here and f32 on the reference\'s CPU, so a seeded run is not the '
+                                                  'reference\'s run: on tests/golden/search_9x9_w512.npz >= 95 % of the envs pick the reference\'s first action and >= 60 % have '
+                                                  'identical root visit counts (tests/test_reference_fixtures.py)',
+                       'parity_target': 'reference cpu.cpp as g++ -O1 and up compiles it (powf(bot, 2) folded to bot*bot); the reference\'s own JIT build passes no -O flag and calls '
+                                        'libm powf, which differs from bot*bot on 0.036 % of floats (oracle/liboracle_powf.so keeps that variant; the HIP path does not)',
+                       'fold_fast': bool(_native.fold_fast(torch.device('cuda', local))),
+                       'value_fold_safe': value_fold_safe,   # the ISA-padded fold (two wait states per dependent DPP step): what a device that fails bl_selftest() runs
                        'value_reference_rng_protocol': value,          # the headline IS on the reference's stream (MoveRng above)
                        'value_rand_like_call_by_call': value_torch_rng,  # TorchRng: the same stream drawn with T-1 separate launches
                        'value_after_self_play_drift': drifted,

@@ -17,7 +17,7 @@ _vp, _i = ctypes.c_void_p, ctypes.c_int
 
 class Tune(ctypes.Structure):
     """bl_tune_t: explicit tuning choices (zero = defaults); results never depend on them."""
-    _fields_ = [(k, _i) for k in ('fold_fast', 'expand_waves', 'expand_deep', 'expand_legacy', 'group', 'mlp_no_xcd', 'lazy_init', 'expand_envs', 'expand_help')]
+    _fields_ = [(k, _i) for k in ('fold_fast', 'expand_waves', 'expand_deep', 'expand_legacy', 'group', 'mlp_no_xcd', 'lazy_init', 'expand_envs', 'expand_help', 'powf_libm')]
 
 
 class Search(ctypes.Structure):
@@ -62,6 +62,7 @@ SYMBOLS = {
     'bl_copy_many': (_i, [_vp, _i, _vp]),
     'bl_rand_block': (_i, [_vp, _i, ctypes.c_long, ctypes.c_long, _i, ctypes.c_ulonglong, ctypes.c_ulonglong, ctypes.c_uint, _i, _i, _vp]),
     'bl_selftest': (_i, [_vp]),
+    'bl_powf2': (_i, [_vp, _vp, ctypes.c_long, _vp]),
 }
 
 _lib = None
@@ -120,7 +121,7 @@ def tune(device=None):
     return Tune(fold_fast=fold_fast(device) if device is not None else 0, expand_waves=_env_int('BL_EXPAND_WAVES'),
                 expand_deep=_env_int('BL_EXPAND_DEEP'), expand_legacy=_env_int('BL_EXPAND_LEGACY'), group=_env_int('BL_FORCE_GROUP'),
                 mlp_no_xcd=int(os.environ.get('BL_MLP_XCD', '1') == '0'), expand_envs=_env_int('BL_EXPAND_ENVS'),
-                expand_help=_env_int('BL_EXPAND_HELP'))
+                expand_help=_env_int('BL_EXPAND_HELP'), powf_libm=_env_int('BL_POWF_LIBM'))
 
 
 GENLIBPATH = os.path.join(HERE, 'libbl_torchgen.so')

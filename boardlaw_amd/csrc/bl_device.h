@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <math.h>
+#include "bl_powf.h"
 
 #pragma clang fp contract(off)
 
@@ -101,6 +102,13 @@ __device__ __forceinline__ void ieee_div_n(const float (&a)[N], const float (&b)
 }
 
 __host__ __device__ __forceinline__ int al16(int x) { return (x + 15) & ~15; }
+
+// The derivative term's denominator, cpu.cpp:60 `powf(bot, 2)`: g++ folds it to bot * bot from -O1 on (the default parity target,
+// DESIGN.md section 2); the reference's own JIT build passes no -O flag and calls libm -- bl_tune_t.powf_libm selects that
+// (bl_powf.h: glibc 2.35's powf restated, equal to the host libm's on all 2^32 floats; wave-uniform branch).
+__device__ __forceinline__ float g_denominator(float bot, int powf_libm) {
+    return powf_libm ? bl_powf2_glibc(bot, BLP_LOG2_TAB, BLP_EXP2_TAB) : bot * bot;
+}
 
 template <int CTRL, int RM>
 __device__ __forceinline__ int dpp_i(int old, int v) { return __builtin_amdgcn_update_dpp(old, v, CTRL, RM, 0xf, false); }
@@ -221,6 +229,7 @@ struct Search {
     int16_t* fav;                                // (B,T) most visited child of a node, a hint for bl_expand.hip's speculative batches
     const int32_t* n_active;                     // device scalar or null: envs >= *n_active sit the simulation out
     int lazy;                                    // bl_tune_t.lazy_init: bl_sim_expand #sim gives slot `sim` its reset values
+    int powf_libm;                               // bl_tune_t.powf_libm: the g term's denominator is glibc's powf(bot, 2), not bot * bot
 };
 
 // bl_tune_t.lazy_init, called by one wave of env b at the end of bl_sim_expand #sim: what MCTS.__init__ (mcts/__init__.py:43-67)

@@ -245,7 +245,7 @@ __global__ void __launch_bounds__(BL_WAVE * NW, (RMAX <= 3 ? 8 : 4)) sim_expand2
                     const bool isS = lowhalf != ((r & 1) != 0);
                     const float bot = alpha - q[r];
                     num[r] = isS ? top[r] : -top[r];
-                    den[r] = isS ? bot : bot * bot;
+                    den[r] = isS ? bot : g_denominator(bot, s.powf_libm);
                 }
                 ieee_div_n<RR>(num, den, quo);
 #pragma unroll
@@ -285,7 +285,7 @@ __global__ void __launch_bounds__(BL_WAVE * NW, (RMAX <= 3 ? 8 : 4)) sim_expand2
                     const bool isS = lowhalf != ((r & 1) != 0);
                     const float bot = alpha - q[r];
                     const float num = isS ? top[r] : -top[r];
-                    const float den = isS ? bot : bot * bot;
+                    const float den = isS ? bot : g_denominator(bot, s.powf_libm);
                     term[r] = in[r] ? num / den : 0.f;                    // prob(a), cuda.cu:23-25, resp. its derivative term
                 }
             }
@@ -476,11 +476,18 @@ __global__ void __launch_bounds__(BL_WAVE * NW, (RMAX <= 3 ? 8 : 4)) sim_expand2
 // (evaluate_node is the batch evaluation of sim_expand2_kernel, instruction for instruction); which wave computes it changes
 // nothing.
 //
-// All waves of the workgroup run the batch loop in step (two barriers per batch).  Shared state in LDS: per env the slot
-// statistics a joining wave needs (st_*: q, n, info, uniform, fav of the env's 64 slots), the descent's state (es), the batch's
-// results (res).  Who works for whom is computed by every wave from that state with the same deterministic rule, so no
-// wave ever waits for an assignment: own waves keep positions 0 and 1; a free wave stays with the env it joined while that
-// goes on, else joins the env (at or beyond level `help_thresh`) with the fewest waves, the deepest first among equals.
+// No workgroup barrier couples the envs (a first version that ran all waves of a workgroup through the batches in step, two
+// barriers per batch, was bit-exact and 20-50 % SLOWER: under eight waves per SIMD the SIMDs arbitrate oldest-first, waves
+// advance at very different rates, and a barrier hands every env the pace of the workgroup's slowest wave --
+// profiles/r04_shared_wg_lockstep_ab.txt).  An env's even wave is its LEADER: it owns the descent's state, lays out a batch
+// (task[e][k] = node, info, uniform for position k), publishes it with one LDS word (ev[e][EV_GO] = batch number, positions),
+// evaluates position 0 itself and walks through the results, waiting for position k's (res[e][k], tagged with the batch
+// number) only when the walk gets there.  Every other wave is a MEMBER: it polls its env's EV_GO word (s_sleep between
+// polls), evaluates the node of its position and posts the result; when its env has ended (EV_FIN) it takes a ticket of another
+// env of the workgroup that still goes (at or beyond level `help_thresh`, below `maxw` waves; the fewest waves first, the deepest
+// among equals) and serves that one -- the leader counts tickets when it lays out the next batch.  A leader expands its env
+// as soon as the descent has ended (the board goes through LDS with wave-scope fences) and then becomes a member itself.
+// Ordering: a wave's LDS operations execute in order; payload and flag are separated by workgroup-scope release/acquire fences.
 // ------------------------------------------------------------------------------------------------------------------
 template <int RMAX, bool FAST>
 __device__ __forceinline__ void evaluate_node(const Search& s, const long envbase, const int A, const int t, const int tinfo, const float rnd,
@@ -537,7 +544,7 @@ __device__ __forceinline__ void evaluate_node(const Search& s, const long envbas
                 const bool isS = lowhalf != ((r & 1) != 0);
                 const float bot = alpha - q[r];
                 num[r] = isS ? top[r] : -top[r];
-                den[r] = isS ? bot : bot * bot;
+                den[r] = isS ? bot : g_denominator(bot, s.powf_libm);
             }
             ieee_div_n<RR>(num, den, quo);
 #pragma unroll
@@ -588,41 +595,64 @@ __device__ __forceinline__ void evaluate_node(const Search& s, const long envbas
     }
 }
 
-// es[e][...]: the descent of env e of the workgroup
-enum { ES_T = 0, ES_TINFO, ES_NLEV, ES_GOING, ES_PARENT, ES_ACTION, ES_SEL, ES_B, ES_CPUCT, ES_WORDS = 12 };
+// LDS words of env e of the workgroup
+enum { EV_GO = 0,       // leader -> members: batch number << 8 | positions of the batch; EV_FIN once the descent has ended
+       EV_NREQ,         // tickets taken by joining waves (position = 2 + ticket)
+       EV_NLEV, EV_GOING, EV_B, EV_CPUCT, EV_WORDS = 8 };
+#define EV_FIN 0x7fffffff
+#define BLX_POLL_LIMIT (1 << 20)     // a wave never waits for ever: a protocol error ends in wrong results (which the parity tests see), not in a hung GPU
+
+__device__ __forceinline__ int lds_peek(const int* p) {     // one broadcast LDS read, wave-uniform
+    return __builtin_amdgcn_readfirstlane(__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+}
+// Payload before flag, flag before payload: a wave's DS operations execute in order, so all that is needed is that the COMPILER keeps
+// the order -- a workgroup-scope fence would also wait for the wave's outstanding GLOBAL stores (s_waitcnt vmcnt(0): the path[]
+// store of every level, a memory round trip per batch -- the first version of this kernel lost 3 us per launch to it).
+__device__ __forceinline__ void lds_order() { asm volatile("" ::: "memory"); }
+__device__ __forceinline__ void lds_poke(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 
 template <int RMAX, bool FAST, int NE>
 __global__ void __launch_bounds__(BL_WAVE * 2 * NE, (RMAX <= 3 ? 8 : 4)) sim_expand4_kernel(Search s, int sim, const uint16_t* rands, int16_t* leaves_out,
                                                                                         void* obs_out, uint8_t* valid_out, int32_t* leaf_seats_out,
-                                                                                        int deep_thresh, int help_thresh) {
+                                                                                        int deep_thresh, int help_thresh, int maxw) {
     constexpr int W = 2 * NE;                       // waves of the workgroup = the most positions a batch can have
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    __shared__ int st_qp[NE][64], st_nn[NE][64], st_info[NE][64], st_rd[NE][64], st_fav[NE][64];
-    __shared__ __attribute__((aligned(16))) int es[NE][ES_WORDS];
-    __shared__ __attribute__((aligned(16))) int res[NE][W][4];
+    __shared__ int st_qp[NE][64], st_nn[NE][64];    // what a joining wave needs of env e's slots: normalised q (both seats) and n
+    __shared__ __attribute__((aligned(16))) int ev[NE][EV_WORDS];
+    __shared__ __attribute__((aligned(16))) int task[NE][W][4];     // leader -> position k: {node, info, uniform (f16 bits), -}
+    __shared__ __attribute__((aligned(16))) int res[NE][W][4];      // position k -> leader: {action, child, index in the row, batch number}
+    __shared__ int nfinished, wantmask;             // envs whose descent has ended; bit e: env e would take another wave
     const int S = s.S, A = S * S, T = s.T;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int nact = active_envs(s);
+    if (threadIdx.x == 0) wantmask = 0;
+    for (int i = threadIdx.x; i < NE * EV_WORDS; i += blockDim.x) ((int*)ev)[i] = 0;
+    for (int i = threadIdx.x; i < NE * W * 4; i += blockDim.x) { ((int*)res)[i] = 0; ((int*)task)[i] = 0; }
+    if (threadIdx.x == 0) nfinished = 0;
+    __syncthreads();                                 // the only workgroup barrier: from here on envs run independently of each other
 
-    // ---- prologue: wave w loads the slot statistics of env w / 2 (lane t <-> slot t) and normalises q (transition_q,
-    // cuda.cu:101-105, both seats, once per launch); the even wave publishes them and the descent's start
-    uint32_t qp; int nn, info, rd, fav;
-    int cur = wave >> 1;                                               // the env whose statistics this wave's registers hold
+    // ---- prologue: wave w belongs to env w / 2; the even wave is its leader.  Slot statistics: lane t <-> slot t; transition_q
+    // (cuda.cu:101-105) of every slot, both seats, once per launch
+    const int e0 = wave >> 1;
+    const bool leader = !(wave & 1);
+    uint32_t qp; int nn, info = 0, rd = 0, fav = -1;
+    int b0;
     {
         // env e of workgroup g: launch slot g + e * gridDim.x -- with gridDim.x a multiple of 8 all NE envs of a workgroup are
         // = g (mod 8), the XCD the workgroup runs on (bl_mlp.hip forms its row tiles by env mod 8)
-        const int slot = blockIdx.x + cur * gridDim.x;
+        const int slot = blockIdx.x + e0 * gridDim.x;
         int b = slot < s.B ? (s.order ? s.order[slot] : slot) : s.B;
-        if (b >= nact) b = -1;
-        b = __builtin_amdgcn_readfirstlane(b);
-        const long envbase = (long)(b < 0 ? 0 : b) * T;
-        uint32_t wp = 0; nn = 0; info = 0; rd = 0; fav = -1;
-        if (b >= 0 && lane < T) {
+        if (b >= active_envs(s)) b = -1;
+        b0 = __builtin_amdgcn_readfirstlane(b);
+        const long envbase = (long)(b0 < 0 ? 0 : b0) * T;
+        uint32_t wp = 0; nn = 0;
+        if (b0 >= 0 && lane < T) {
             wp = *(const uint32_t*)(s.w + (envbase + lane) * 2);
             nn = s.n[envbase + lane];
-            info = (int)(uint16_t)s.nk[envbase + lane] | ((s.seats[envbase + lane] & 1) << 16) | ((s.terminal[envbase + lane] ? 1 : 0) << 17);
-            rd = rands[envbase + lane];
-            fav = s.fav[envbase + lane];
+            if (leader) {
+                info = (int)(uint16_t)s.nk[envbase + lane] | ((s.seats[envbase + lane] & 1) << 16) | ((s.terminal[envbase + lane] ? 1 : 0) << 17);
+                rd = rands[envbase + lane];
+                fav = s.fav[envbase + lane];
+            }
         }
         float lo, hi;
         load_qrange(s.qrange + (long)BL_QWORDS * sim, lo, hi);
@@ -630,123 +660,79 @@ __global__ void __launch_bounds__(BL_WAVE * 2 * NE, (RMAX <= 3 ? 8 : 4)) sim_exp
         const float den = (float)nn + 1.e-4f;
         const float q0 = h2f((uint16_t)wp) / den, q1 = h2f((uint16_t)(wp >> 16)) / den;
         qp = (uint32_t)f2h((q0 - lo) / rden) | ((uint32_t)f2h((q1 - lo) / rden) << 16);
-        if (!(wave & 1)) {
-            st_qp[cur][lane] = (int)qp; st_nn[cur][lane] = nn; st_info[cur][lane] = info; st_rd[cur][lane] = rd; st_fav[cur][lane] = fav;
-            const int info0 = __builtin_amdgcn_readfirstlane(info);
-            if (lane == 0) {
-                es[cur][ES_T] = 0; es[cur][ES_TINFO] = info0; es[cur][ES_NLEV] = 0;
-                es[cur][ES_GOING] = (b >= 0 && !((info0 >> 17) & 1) && T > 0) ? 1 : 0;
-                es[cur][ES_PARENT] = 0; es[cur][ES_ACTION] = -1; es[cur][ES_SEL] = 0; es[cur][ES_B] = b;
-                es[cur][ES_CPUCT] = b >= 0 ? (int)s.c_puct[b] : 0;
-            }
-        }
     }
-    __syncthreads();
+    int att = e0, pos = 1, lastseq = 0;                // the env this wave works for (-1: none), its position, the last batch seen
+    int ab = b0;                                       // ... that env's index and c_puct
+    float acpuct = b0 >= 0 ? h2f(s.c_puct[b0]) : 0.f;
 
-    // who works for whom, replicated in every wave: aenv[w] / apos[w] = env and batch position of wave w (-1: idle)
-    int aenv[W], apos[W];
-#pragma unroll
-    for (int w = 0; w < W; w++) { aenv[w] = w >> 1; apos[w] = w & 1; }
-
-    for (int batch = 0; batch <= T; batch++) {
-        // ---- the descents' state
-        int going[NE], nlev[NE], anygoing = 0;
-#pragma unroll
-        for (int e = 0; e < NE; e++) {
-            going[e] = __builtin_amdgcn_readfirstlane(es[e][ES_GOING]);
-            nlev[e] = __builtin_amdgcn_readfirstlane(es[e][ES_NLEV]);
-            anygoing |= going[e];
+    if (leader) {
+        const int e = e0, b = b0;
+        const long envbase = (long)(b < 0 ? 0 : b) * T;
+        int16_t* path = s.path ? s.path + (long)b * (T + 2) : nullptr;
+        int t = 0, tinfo = __builtin_amdgcn_readfirstlane(info), nlev = 0, parent = 0, action = -1, sel_e = 0, seq = 0;
+        bool live = b >= 0, wants = false;
+        st_qp[e][lane] = (int)qp; st_nn[e][lane] = nn;
+        if (lane == 0) {
+            lds_poke(&ev[e][EV_B], b); lds_poke(&ev[e][EV_CPUCT], b >= 0 ? (int)s.c_puct[b] : 0); lds_poke(&ev[e][EV_NLEV], 0);
         }
-        if (!anygoing) break;
-        // ---- assignment (the same computation in every wave)
-        int cnt[NE];
-#pragma unroll
-        for (int e = 0; e < NE; e++) cnt[e] = going[e] ? 2 : 0;
-#pragma unroll
-        for (int w = 0; w < W; w++) {
-            if (going[w >> 1]) { aenv[w] = w >> 1; apos[w] = w & 1; }
-            else {
-                bool keeps = false;
-#pragma unroll
-                for (int e = 0; e < NE; e++) if (aenv[w] == e && e != (w >> 1) && going[e]) keeps = true;
-                if (!keeps) aenv[w] = -1;
-            }
-        }
-#pragma unroll
-        for (int w = 0; w < W; w++) {
-            if (!going[w >> 1] && aenv[w] >= 0) {
-#pragma unroll
-                for (int e = 0; e < NE; e++) if (aenv[w] == e) cnt[e] = cnt[e] > apos[w] + 1 ? cnt[e] : apos[w] + 1;
-            }
-        }
-#pragma unroll
-        for (int w = 0; w < W; w++) {
-            if (!going[w >> 1] && aenv[w] < 0) {
-                int best = -1, bestcnt = 0, bestlev = 0;
-#pragma unroll
-                for (int e = 0; e < NE; e++) {
-                    if (going[e] && nlev[e] >= help_thresh && cnt[e] < W && (best < 0 || cnt[e] < bestcnt || (cnt[e] == bestcnt && nlev[e] > bestlev))) {
-                        best = e; bestcnt = cnt[e]; bestlev = nlev[e];
+        lds_order();
+        if (lane == 0) lds_poke(&ev[e][EV_GOING], (live && !((tinfo >> 17) & 1)) ? 1 : 0);
+        // ---- descend_kernel's loop, cuda.cu:138-182, a batch of up to `cnt` guessed levels at a time
+        for (int batch = 0; batch <= T; batch++) {
+            if (!live || t == -1 || ((tinfo >> 17) & 1) || nlev >= T) break;
+            int cnt = 2 + lds_peek(&ev[e][EV_NREQ]);
+            if (cnt > W) cnt = W;
+            {
+                // free waves look at ONE word between long sleeps: this env's bit says whether it would take another wave
+                const bool w = nlev >= help_thresh && cnt < maxw && cnt < W;
+                if (w != wants) {
+                    wants = w;
+                    if (lane == 0) {
+                        if (w) __hip_atomic_fetch_or(&wantmask, 1 << e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        else __hip_atomic_fetch_and(&wantmask, ~(1 << e), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     }
                 }
-                if (best >= 0) {
-                    aenv[w] = best; apos[w] = bestcnt;
-#pragma unroll
-                    for (int e = 0; e < NE; e++) if (e == best) cnt[e]++;
-                }
             }
-        }
-        int me = -1, mypos = 0, mycnt = 0;
-#pragma unroll
-        for (int w = 0; w < W; w++) if (wave == w) { me = aenv[w]; mypos = apos[w]; }
-#pragma unroll
-        for (int e = 0; e < NE; e++) if (me == e) mycnt = cnt[e];
-
-        int ra = -2, rc = -1, rs = 0;
-        int u[W], uinfo[W];
-        int t = -1, tinfo = 0, lev = 0, b = -1;
-        float cpuct = 0.f;
-        if (me >= 0) {
-            if (me != cur) {                                       // joining another env: its slot statistics
-                qp = (uint32_t)st_qp[me][lane]; nn = st_nn[me][lane]; info = st_info[me][lane]; rd = st_rd[me][lane]; fav = st_fav[me][lane];
-                cur = me;
-            }
-            t = __builtin_amdgcn_readfirstlane(es[me][ES_T]); tinfo = __builtin_amdgcn_readfirstlane(es[me][ES_TINFO]);
-            lev = __builtin_amdgcn_readfirstlane(es[me][ES_NLEV]); b = __builtin_amdgcn_readfirstlane(es[me][ES_B]);
-            cpuct = h2f((uint16_t)__builtin_amdgcn_readfirstlane(es[me][ES_CPUCT]));
             // the nodes of this batch: the current one and its guessed continuation
+            int u[W], uinfo[W];
             u[0] = t; uinfo[0] = tinfo;
 #pragma unroll
             for (int k = 1; k < W; k++) {
                 u[k] = -1; uinfo[k] = 0;
-                if (k < mycnt && lev >= deep_thresh && u[k - 1] != -1 && !((uinfo[k - 1] >> 17) & 1)) {
+                if (k < cnt && nlev >= deep_thresh && u[k - 1] != -1 && !((uinfo[k - 1] >> 17) & 1)) {
                     u[k] = __builtin_amdgcn_readfirstlane(__builtin_amdgcn_readlane(fav, u[k - 1] & 63));
                     if (u[k] != -1) uinfo[k] = __builtin_amdgcn_readfirstlane(__builtin_amdgcn_readlane(info, u[k] & 63));
                 }
             }
-            int my = -1, myinfo = 0;
+            seq++;
 #pragma unroll
-            for (int k = 0; k < W; k++) if (mypos == k) { my = u[k]; myinfo = uinfo[k]; }
-            if (my != -1 && !((myinfo >> 17) & 1)) {
-                const float rnd = h2f((uint16_t)__builtin_amdgcn_readfirstlane(__builtin_amdgcn_readlane(rd, my & 63)));
-                evaluate_node<RMAX, FAST>(s, (long)b * T, A, my, myinfo, rnd, cpuct, qp, nn, ra, rc, rs);
+            for (int k = 1; k < W; k++) {
+                if (k < cnt) {
+                    const int rk = u[k] != -1 ? __builtin_amdgcn_readlane(rd, u[k] & 63) : 0;
+                    if (lane == 0) { task[e][k][0] = u[k]; task[e][k][1] = uinfo[k]; task[e][k][2] = rk; }
+                }
             }
-            if (lane == 0) { res[me][mypos][0] = ra; res[me][mypos][1] = rc; res[me][mypos][2] = rs; }
-        }
-        __syncthreads();
-        // ---- follow the drawn edges through the batch (every wave of the env, the same scalar walk; position 0 publishes)
-        if (me >= 0) {
-            int16_t* path = s.path ? s.path + (long)b * (T + 2) : nullptr;
-            int parent = 0, action = -1, sel_e = 0;
-            bool live = true;
+            lds_order();
+            if (lane == 0) { lds_poke(&ev[e][EV_GO], (seq << 8) | cnt); lds_poke(&ev[e][EV_NLEV], nlev); }
+            int ra, rc, rs;
+            {
+                const float rnd = h2f((uint16_t)__builtin_amdgcn_readfirstlane(__builtin_amdgcn_readlane(rd, t & 63)));
+                evaluate_node<RMAX, FAST>(s, envbase, A, t, tinfo, rnd, acpuct, qp, nn, ra, rc, rs);
+            }
+            // follow the drawn edges through the batch; a position's result is waited for only when the walk gets there
 #pragma unroll
             for (int k = 0; k < W; k++) {
-                if (k < mycnt) {
-                    const int a_k = __builtin_amdgcn_readfirstlane(res[me][k][0]), c_k = __builtin_amdgcn_readfirstlane(res[me][k][1]);
-                    const int s_k = __builtin_amdgcn_readfirstlane(res[me][k][2]);
+                if (k < cnt) {
+                    int a_k = ra, c_k = rc, s_k = rs;
+                    if (k > 0) {
+                        int polls = 0;
+                        while (lds_peek(&res[e][k][3]) != seq && ++polls < BLX_POLL_LIMIT) __builtin_amdgcn_s_sleep(1);
+                        lds_order();
+                        a_k = lds_peek(&res[e][k][0]); c_k = lds_peek(&res[e][k][1]); s_k = lds_peek(&res[e][k][2]);
+                    }
                     const int node = u[k];
-                    if (path && mypos == 0 && lane == 0) path[1 + lev] = (int16_t)node;
-                    lev++;
+                    if (path && lane == 0) path[1 + nlev] = (int16_t)node;
+                    nlev++;
                     parent = node; sel_e = s_k;
                     if (a_k < 0) { action = -1; live = false; break; }       // no action with positive probability: the reference would index [-1]
                     action = a_k;
@@ -756,78 +742,114 @@ __global__ void __launch_bounds__(BL_WAVE * 2 * NE, (RMAX <= 3 ? 8 : 4)) sim_exp
                         const int f_old = __builtin_amdgcn_readfirstlane(__builtin_amdgcn_readlane(fav, node & 63));
                         bool upd = f_old == -1;
                         if (!upd) upd = __builtin_amdgcn_readlane(nn, cnew & 63) + 2 >= __builtin_amdgcn_readlane(nn, f_old & 63);
-                        if (upd) {
-                            if (lane == (node & 63)) fav = cnew;
-                            if (mypos == 0 && lane == 0) st_fav[me][node & 63] = cnew;
-                        }
+                        if (upd && lane == (node & 63)) fav = cnew;
                     }
                     t = c_k;
                     if (t == -1) break;
                     tinfo = __builtin_amdgcn_readfirstlane(__builtin_amdgcn_readlane(info, t & 63));
                     if ((tinfo >> 17) & 1) break;
-                    if (!(k + 1 < mycnt && u[k + 1 < W ? k + 1 : 0] == t)) break;      // the guess ends here: next batch starts at t
+                    if (!(k + 1 < cnt && u[k + 1 < W ? k + 1 : 0] == t)) break;      // the guess ends here: next batch starts at t
                 }
             }
-            if (mypos == 0 && lane == 0) {
-                es[me][ES_T] = t; es[me][ES_TINFO] = tinfo; es[me][ES_NLEV] = lev;
-                es[me][ES_GOING] = (live && t != -1 && !((tinfo >> 17) & 1) && lev < T) ? 1 : 0;
-                es[me][ES_PARENT] = parent; es[me][ES_ACTION] = action; es[me][ES_SEL] = sel_e;
+        }
+        if (lane == 0) {
+            lds_poke(&ev[e][EV_GOING], 0); lds_poke(&ev[e][EV_GO], EV_FIN);
+            if (wants) __hip_atomic_fetch_and(&wantmask, ~(1 << e), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_fetch_add(&nfinished, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        if (b >= 0) {
+            // ---- leaves = children[envs, parents, actions]; leaves[leaves == -1] = sim (mcts/__init__.py:117-122); Hex.step + observe
+            if (action < 0) action = 0;
+            if (lane < T) s.fav[envbase + lane] = (int16_t)fav;
+            uint8_t* cells = (uint8_t*)smem + (size_t)e * al16(A);
+            const int nxt = t;
+            const int leaf = (nxt == -1) ? sim : nxt;
+            if (s.lazy) lazy_slot_reset(s, envbase, sim, A, nxt == -1, lane);
+            if (lane == 0) {
+                s.children[(envbase + parent) * A + action] = (int16_t)leaf;
+                s.parents[envbase + leaf] = (int16_t)parent;
+                s.relation[envbase + leaf] = (int16_t)action;
+                if (nxt == -1 && nlev > 0) ((uint16_t*)(s.cca + (envbase + parent) * A + sel_e))[1] = (uint16_t)leaf;   // the compacted row's child field
+            }
+            const int seat = s.seats[envbase + parent];
+            const uint8_t* src = s.boards + (envbase + parent) * A;
+            for (int a = lane; a < A; a += 64) cells[a] = src[a];
+            board_sync<true>();
+            const int win = hex_step_group<64, true>(cells, S, seat, action, true, lane);
+            const bool term = win != 0;                                          // Hex.step tail, hex/__init__.py:183-190
+            const int new_seat = term ? 0 : 1 - seat;
+            uint8_t* dst = s.boards + (envbase + leaf) * A;
+            const float invS = 1.0f / (float)S;
+            const bool flip = new_seat == 1;
+            for (int a = lane; a < A; a += 64) dst[a] = term ? (uint8_t)0 : cells[a];
+            for (int a = lane; a < A; a += 64) {
+                const int i = (int)(((float)a + 0.5f) * invS), j = a - i * S;
+                const int color = term ? 2 : color_of(cells[flip ? j * S + i : a]);
+                const int ch = color < 2 ? (flip ? 1 - color : color) : 2;
+                if (s.obs_f16) ((uint32_t*)obs_out)[(long)b * A + a] = ch == 0 ? 0x00003c00u : (ch == 1 ? 0x3c000000u : 0u);   // f16 1.0 = 0x3c00
+                else ((float2*)obs_out)[(long)b * A + a] = make_float2(ch == 0 ? 1.f : 0.f, ch == 1 ? 1.f : 0.f);
+                valid_out[(long)b * A + a] = color == 2;
+            }
+            if (lane == 0) {
+                s.seats[envbase + leaf] = new_seat;
+                s.terminal[envbase + leaf] = term;
+                s.rewards[(envbase + leaf) * 2 + 0] = f2h((float)win);
+                s.rewards[(envbase + leaf) * 2 + 1] = f2h((float)(-win));
+                leaves_out[b] = (int16_t)leaf;
+                leaf_seats_out[b] = new_seat;
+                if (path) {
+                    path[1 + nlev] = (int16_t)leaf;
+                    path[0] = (int16_t)(nlev + 1);
+                }
             }
         }
-        __syncthreads();
+        att = -1;                                     // the leader is free now, too
     }
-    if (wave >= NE) return;
 
-    // ---- wave e < NE expands env e: leaves = children[envs, parents, actions]; leaves[leaves == -1] = sim (mcts/__init__.py:117-122)
-    const int e = wave;
-    const int b = __builtin_amdgcn_readfirstlane(es[e][ES_B]);
-    if (b < 0) return;
-    const long envbase = (long)b * T;
-    const int nlev = __builtin_amdgcn_readfirstlane(es[e][ES_NLEV]), parent = __builtin_amdgcn_readfirstlane(es[e][ES_PARENT]);
-    const int sel_e = __builtin_amdgcn_readfirstlane(es[e][ES_SEL]), nxt = __builtin_amdgcn_readfirstlane(es[e][ES_T]);
-    int action = __builtin_amdgcn_readfirstlane(es[e][ES_ACTION]);
-    if (action < 0) action = 0;
-    if (lane < T) s.fav[envbase + lane] = (int16_t)st_fav[e][lane];
-    int16_t* path = s.path ? s.path + (long)b * (T + 2) : nullptr;
-    uint8_t* cells = (uint8_t*)smem + (size_t)e * al16(A);
-    const int leaf = (nxt == -1) ? sim : nxt;
-    if (s.lazy) lazy_slot_reset(s, envbase, sim, A, nxt == -1, lane);
-    if (lane == 0) {
-        s.children[(envbase + parent) * A + action] = (int16_t)leaf;
-        s.parents[envbase + leaf] = (int16_t)parent;
-        s.relation[envbase + leaf] = (int16_t)action;
-        if (nxt == -1 && nlev > 0) ((uint16_t*)(s.cca + (envbase + parent) * A + sel_e))[1] = (uint16_t)leaf;   // the compacted row's child field
-    }
-    const int seat = s.seats[envbase + parent];
-    const uint8_t* src = s.boards + (envbase + parent) * A;
-    for (int a = lane; a < A; a += 64) cells[a] = src[a];
-    board_sync<true>();
-    const int win = hex_step_group<64, true>(cells, S, seat, action, true, lane);
-    // Hex.step tail, hex/__init__.py:183-190
-    const bool term = win != 0;
-    const int new_seat = term ? 0 : 1 - seat;
-    uint8_t* dst = s.boards + (envbase + leaf) * A;
-    const float invS = 1.0f / (float)S;
-    const bool flip = new_seat == 1;
-    for (int a = lane; a < A; a += 64) dst[a] = term ? (uint8_t)0 : cells[a];
-    for (int a = lane; a < A; a += 64) {
-        const int i = (int)(((float)a + 0.5f) * invS), j = a - i * S;
-        const int color = term ? 2 : color_of(cells[flip ? j * S + i : a]);
-        const int ch = color < 2 ? (flip ? 1 - color : color) : 2;
-        if (s.obs_f16) ((uint32_t*)obs_out)[(long)b * A + a] = ch == 0 ? 0x00003c00u : (ch == 1 ? 0x3c000000u : 0u);   // f16 1.0 = 0x3c00
-        else ((float2*)obs_out)[(long)b * A + a] = make_float2(ch == 0 ? 1.f : 0.f, ch == 1 ? 1.f : 0.f);
-        valid_out[(long)b * A + a] = color == 2;
-    }
-    if (lane == 0) {
-        s.seats[envbase + leaf] = new_seat;
-        s.terminal[envbase + leaf] = term;
-        s.rewards[(envbase + leaf) * 2 + 0] = f2h((float)win);
-        s.rewards[(envbase + leaf) * 2 + 1] = f2h((float)(-win));
-        leaves_out[b] = (int16_t)leaf;
-        leaf_seats_out[b] = new_seat;
-        if (path) {
-            path[1 + nlev] = (int16_t)leaf;
-            path[0] = (int16_t)(nlev + 1);
+    // ---- a member's life: serve the env it is attached to until that ends, then join another one of the workgroup that still goes
+    for (int polls = 0; polls < BLX_POLL_LIMIT; polls++) {
+        if (att >= 0) {
+            const int g = lds_peek(&ev[att][EV_GO]);
+            if (g == EV_FIN) { att = -1; continue; }
+            const int sq = g >> 8, cnt = g & 0xff;
+            if (sq == lastseq) { __builtin_amdgcn_s_sleep(1); continue; }
+            lastseq = sq;
+            if (pos >= cnt) continue;                 // joined after this batch was laid out
+            lds_order();
+            const int node = lds_peek(&task[att][pos][0]), ninfo = lds_peek(&task[att][pos][1]), rbits = lds_peek(&task[att][pos][2]);
+            if (lds_peek(&ev[att][EV_GO]) != g) { lastseq = sq - 1; continue; }     // the leader has moved on meanwhile: read again
+            int ra = -2, rc = -1, rs = 0;
+            if (node != -1 && !((ninfo >> 17) & 1)) evaluate_node<RMAX, FAST>(s, (long)ab * T, A, node, ninfo, h2f((uint16_t)rbits), acpuct, qp, nn, ra, rc, rs);
+            if (lane == 0) { res[att][pos][0] = ra; res[att][pos][1] = rc; res[att][pos][2] = rs; }
+            lds_order();
+            if (lane == 0) lds_poke(&res[att][pos][3], sq);
+            polls = 0;
+        } else {
+            if (lds_peek(&nfinished) >= NE) return;
+            const int want = lds_peek(&wantmask);
+            if (!want) { __builtin_amdgcn_s_sleep(32); continue; }      // nothing to do: ~2k cycles asleep per look, next to no issue slots
+            // among the envs that would take a wave (at or beyond level help_thresh, below maxw waves): the fewest waves, the deepest among equals
+            int best = -1, bestcnt = 0, bestlev = 0;
+#pragma unroll
+            for (int e = 0; e < NE; e++) {
+                if ((want >> e) & 1) {
+                    const int going = lds_peek(&ev[e][EV_GOING]), lev = lds_peek(&ev[e][EV_NLEV]), c = 2 + lds_peek(&ev[e][EV_NREQ]);
+                    if (going && c < maxw && c < W && (best < 0 || c < bestcnt || (c == bestcnt && lev > bestlev))) { best = e; bestcnt = c; bestlev = lev; }
+                }
+            }
+            if (best < 0) { __builtin_amdgcn_s_sleep(8); continue; }
+            // the batch number BEFORE the ticket: every later batch that counts this position in is served
+            const int g = lds_peek(&ev[best][EV_GO]);
+            if (g == EV_FIN) continue;
+            lastseq = g >> 8;
+            int ticket = 0;
+            if (lane == 0) ticket = __hip_atomic_fetch_add(&ev[best][EV_NREQ], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            ticket = __builtin_amdgcn_readfirstlane(ticket);
+            att = best; pos = 2 + ticket;
+            lds_order();
+            qp = (uint32_t)st_qp[att][lane]; nn = st_nn[att][lane];
+            ab = lds_peek(&ev[att][EV_B]); acpuct = h2f((uint16_t)lds_peek(&ev[att][EV_CPUCT]));
+            if (pos >= W) att = -1;                   // cannot happen (a workgroup has W - 2 waves besides an env's own two)
         }
     }
 }
@@ -960,7 +982,7 @@ __global__ void __launch_bounds__(BL_WAVE) sim_expand3_kernel(Search s, int sim,
                 for (int r = 0; r < RR; r++) {
                     const float bot = alpha - q[r];
                     num[r] = isS ? top[r] : -top[r];
-                    den[r] = isS ? bot : bot * bot;
+                    den[r] = isS ? bot : g_denominator(bot, s.powf_libm);
                 }
                 ieee_div_n<RR>(num, den, quo);                            // prob(a), cuda.cu:23-25, resp. its derivative term
 #pragma unroll
@@ -1176,8 +1198,8 @@ int bl_expand2_launch(const Search& ss, int sim, const void* rands, int16_t* lea
         // envs per workgroup, two waves each, finished envs' waves help the ones still going (sim_expand4_kernel)
         const dim3 grid4((ss.B + envs - 1) / envs), block4(64 * 2 * envs);
         const size_t lds4 = (size_t)al16(A) * envs;
-#define BLX4(R_, NE_) { if (fast) hipLaunchKernelGGL((sim_expand4_kernel<R_, true, NE_>), grid4, block4, lds4, stream, ss, sim, (const uint16_t*)rands, leaves, obs, valid, leaf_seats, deep_thresh, help_thresh); \
-                        else hipLaunchKernelGGL((sim_expand4_kernel<R_, false, NE_>), grid4, block4, lds4, stream, ss, sim, (const uint16_t*)rands, leaves, obs, valid, leaf_seats, deep_thresh, help_thresh); }
+#define BLX4(R_, NE_) { if (fast) hipLaunchKernelGGL((sim_expand4_kernel<R_, true, NE_>), grid4, block4, lds4, stream, ss, sim, (const uint16_t*)rands, leaves, obs, valid, leaf_seats, deep_thresh, help_thresh & 0xff, ((help_thresh >> 8) & 0xff) ? ((help_thresh >> 8) & 0xff) : 2 * NE_); \
+                        else hipLaunchKernelGGL((sim_expand4_kernel<R_, false, NE_>), grid4, block4, lds4, stream, ss, sim, (const uint16_t*)rands, leaves, obs, valid, leaf_seats, deep_thresh, help_thresh & 0xff, ((help_thresh >> 8) & 0xff) ? ((help_thresh >> 8) & 0xff) : 2 * NE_); }
 #define BLX4E(R_) { if (envs == 2) BLX4(R_, 2) else BLX4(R_, 4) }
         const int need4 = (A + 31) / 32;
         if (need4 <= 1) BLX4E(1) else if (need4 <= 2) BLX4E(2) else if (need4 <= 3) BLX4E(3) else BLX4E(6)

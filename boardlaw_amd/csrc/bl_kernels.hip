@@ -35,6 +35,7 @@ struct Tree {
     const float* exp_table;   // 65536
     int B, T, A, S;
     int seats_i32;
+    int powf_libm;            // bl_tune_t.powf_libm (bl_device.h: g_denominator)
 };
 
 __device__ __forceinline__ int load_seat(const Tree& m, long i) {
@@ -157,7 +158,7 @@ __device__ __forceinline__ int policy_eval(const Tree& m, int b, int t, int seat
                     const float bot = alpha - q[k];
                     prob[k] = top[k] / bot;
                     L.s[a] = prob[k];
-                    L.g[a] = (-top[k]) / (bot * bot);
+                    L.g[a] = (-top[k]) / g_denominator(bot, m.powf_libm);
                 }
             }
         }
@@ -336,7 +337,7 @@ __device__ __forceinline__ int policy_eval_wave(const Tree& m, int b, int t, int
                 const float bot = alpha - cq[k];
                 const bool in = k * 64 + lane < n_c;
                 cprob[k] = in ? ctop[k] / bot : 0.f;        // lanes past the end fold +0: harmless to every earlier lane
-                tg[k] = in ? (-ctop[k]) / (bot * bot) : 0.f;
+                tg[k] = in ? (-ctop[k]) / g_denominator(bot, m.powf_libm) : 0.f;
             }
         }
         if (COUNT) { ti1 = clock64(); tdiv += ti1 - ti0; }
@@ -668,7 +669,7 @@ __global__ void __launch_bounds__(BL_WAVE) sim_expand_kernel(Search s, int sim, 
     Tree m;
     m.logits = s.logits; m.w = s.w; m.n = s.n; m.c_puct = s.c_puct; m.seats = s.seats; m.terminal = s.terminal;
     m.children = s.children; m.qrange = s.qrange + (long)BL_QWORDS * sim; m.exp_table = s.exp_table;
-    m.B = s.B; m.T = T; m.A = A; m.S = 2; m.seats_i32 = 1;
+    m.B = s.B; m.T = T; m.A = A; m.S = 2; m.seats_i32 = 1; m.powf_libm = s.powf_libm;
 
     long long tk0 = 0, tk1 = 0;
     if (COUNT) tk0 = clock64();
@@ -1220,6 +1221,13 @@ int bl_expand2_launch(const Search& ss, int sim, const void* rands, int16_t* lea
 int bl_fold_selftest(int use_fast, hipStream_t stream);
 #define BL_EXPAND_ENVS_DEFAULT 1        // until the A/B of round 4 says otherwise
 
+namespace bl {
+__global__ void __launch_bounds__(256) powf2_kernel(const float* x, float* out, long n) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = g_denominator(x[i], 1);
+}
+}  // namespace bl
+
 extern "C" {
 
 int bl_abi_version(void) { return 3; }
@@ -1292,7 +1300,7 @@ int bl_mcts_descend_tuned(const bl_tune_t* tune, const void* logits, const void*
     if (rc) return rc;
     if (!rands || !parents || !actions) return BL_EINVAL;
     Tree m{(const uint16_t*)logits, (const uint16_t*)w, n, (const uint16_t*)c_puct, seats, terminal, children, qr,
-           exp_table, B, T, A, S, 0};
+           exp_table, B, T, A, S, 0, tune ? tune->powf_libm : 0};
     const int G = pick_group(B, A, tune ? tune->group : 0), K = pick_k(A, G);
     const int per = lds_bytes(A, false);
     const int blocks = (B + 64 / G - 1) / (64 / G);
@@ -1316,7 +1324,7 @@ int bl_mcts_root_tuned(const bl_tune_t* tune, const void* logits, const void* w,
     if (rc) return rc;
     if (!probs) return BL_EINVAL;
     Tree m{(const uint16_t*)logits, (const uint16_t*)w, n, (const uint16_t*)c_puct, seats, terminal, children, qr,
-           exp_table, B, T, A, S, 0};
+           exp_table, B, T, A, S, 0, tune ? tune->powf_libm : 0};
     const int G = pick_group(B, A, tune ? tune->group : 0), K = pick_k(A, G);
     const int per = lds_bytes(A, false);
     const int blocks = (B + 64 / G - 1) / (64 / G);
@@ -1394,7 +1402,7 @@ static Search to_search(const bl_search_t* s) {
     return Search{(uint16_t*)s->logits, (uint16_t*)s->v, (uint16_t*)s->w, s->n, s->children, s->parents, s->relation,
                   (uint16_t*)s->rewards, s->terminal, s->boards, s->seats, (const uint16_t*)s->c_puct, s->qrange,
                   s->exp_table, s->B, s->T, s->boardsize, s->obs_f16, s->path, s->order, s->prio_thresh,
-                  s->cpi, s->cca, s->nk, s->fav, s->n_active, s->tune.lazy_init};
+                  s->cpi, s->cca, s->nk, s->fav, s->n_active, s->tune.lazy_init, s->tune.powf_libm};
 }
 
 static int sim_expand_impl(const bl_search_t* s, int sim, const void* rands, int16_t* leaves, void* obs, uint8_t* valid,
@@ -1466,6 +1474,12 @@ int bl_sim_compact(const bl_search_t* s, const int16_t* leaves, bl_stream_t stre
     return check_launch();
 }
 
+int bl_powf2(const float* x, float* out, long n, bl_stream_t stream) {
+    if (!x || !out || n <= 0) return BL_EINVAL;
+    hipLaunchKernelGGL(powf2_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, out, n);
+    return check_launch();
+}
+
 int bl_selftest(bl_stream_t stream) {
     const int wrong_safe = bl_fold_selftest(0, (hipStream_t)stream);
     if (wrong_safe != 0) return wrong_safe < 0 ? wrong_safe : BL_ELAUNCH;      // the ISA-compliant fold must be exact
@@ -1526,7 +1540,7 @@ int bl_sim_root(const bl_search_t* s, int sim, void* probs, const void* log_tabl
     if (!probs || sim < 1 || sim > s->T || (logits && !log_table)) return BL_EINVAL;
     const int A = s->boardsize * s->boardsize;
     Tree m{(const uint16_t*)s->logits, (const uint16_t*)s->w, s->n, (const uint16_t*)s->c_puct, s->seats, s->terminal,
-           s->children, s->qrange + (long)BL_QWORDS * sim, s->exp_table, s->B, s->T, A, 2, 1};
+           s->children, s->qrange + (long)BL_QWORDS * sim, s->exp_table, s->B, s->T, A, 2, 1, s->tune.powf_libm};
     const int G = pick_group(s->B, A, s->tune.group), K = pick_k(A, G);
     const int per = lds_bytes(A, false);
     const int blocks = (s->B + 64 / G - 1) / (64 / G);

@@ -101,8 +101,65 @@ def allreduce_qrange(state):
     return state
 
 
+class GradientBucket:
+    """The module's gradients as views of ONE persistent flat fp32 buffer: backward accumulates into the views in place, the
+    all-reduce runs on the buffer where it lies, and the optimiser reads the views -- no per-step `cat`, no per-tensor copies back
+    (round-3 verdict: at 1024x8 the cat/copy form was three extra passes over 35 MB and ~40 launches per step).  The same idea as
+    DDP's gradient_as_bucket_view, with one bucket: FCModel is at most 17.9 M parameters, latency- not bandwidth-bound on xGMI.
+
+    Use `bucket.zero()` instead of `opt.zero_grad()` (which would drop the views), then backward, then `bucket.allreduce()`."""
+
+    def __init__(self, module, always=False, timed=False):
+        """always: run the collective in a one-rank group, too (benchmarks of the code path); timed: bracket every collective with
+        device events (`collective_ms()`)."""
+        self.always, self.events = always, ([] if timed else None)
+        self.params = [p for p in module.parameters() if p.requires_grad]
+        assert self.params and all(p.dtype == torch.float32 for p in self.params), 'GradientBucket: fp32 master parameters (AMP keeps them)'
+        dev = self.params[0].device
+        self.flat = torch.zeros(sum(p.numel() for p in self.params), dtype=torch.float32, device=dev)
+        offset = 0
+        for p in self.params:
+            p.grad = self.flat[offset:offset + p.numel()].view_as(p)
+            offset += p.numel()
+
+    def intact(self):
+        """Whether every .grad still is its view (an `opt.zero_grad()` in between would have replaced them)."""
+        offset = 0
+        for p in self.params:
+            if p.grad is None or p.grad.data_ptr() != self.flat.data_ptr() + 4 * offset:
+                return False
+            offset += p.numel()
+        return True
+
+    def zero(self):
+        self.flat.zero_()
+
+    def allreduce(self):
+        """Averages the bucket over ranks in place: one collective (RCCL on GPUs) and one scaling launch.  No-op without a group."""
+        if not dist.is_initialized() or (dist.get_world_size() == 1 and not self.always):
+            return
+        assert self.intact(), 'GradientBucket: a .grad was replaced (use bucket.zero(), not opt.zero_grad())'
+        timed = self.events is not None and self.flat.is_cuda
+        if timed:
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+        dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
+        self.flat.mul_(1.0 / dist.get_world_size())
+        if timed:
+            b.record()
+            self.events.append((a, b))
+
+    def collective_ms(self):
+        """Device time of every timed all-reduce + scaling so far (synchronises)."""
+        if not self.events:
+            return []
+        torch.cuda.synchronize()
+        return [a.elapsed_time(b) for a, b in self.events]
+
+
 def allreduce_gradients(module):
-    """Averages the module's gradients over ranks with ONE flat all-reduce (RCCL on GPUs).  No-op without a group."""
+    """Averages the module's gradients over ranks with ONE flat all-reduce (RCCL on GPUs).  No-op without a group.  The
+    bucket-less form (a cat, the collective, a copy back per tensor): `GradientBucket` is what the training loop uses."""
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return
     grads = [p.grad for p in module.parameters() if p.grad is not None]

@@ -6,10 +6,17 @@ Multi-GPU: one process per GPU, each with its own env shard; the only collective
 (`parallel.allreduce_gradients`: one flat bucket over RCCL -- the 512x4 network is 1.2 M parameters, a single 4.7 MB
 fp32 bucket, latency- not bandwidth-bound on xGMI's point-to-point links, so bucketing finer would only add launches).
 The reference is single-device; with world size 1 this is its `optimize`."""
+import time
+
 import numpy as np
 import torch
 
 from . import arrdict, learning, parallel
+
+
+def _sync(dev):
+    if dev.type == 'cuda':
+        torch.cuda.synchronize(dev)
 
 
 def as_chunk(buffer, batch_size):
@@ -35,22 +42,30 @@ def losses(network, batch):
     return policy_loss, value_loss
 
 
-def optimize(network, scaler, opt, batch, sync_gradients=True):
-    """One learner step (main.py:76-98).  Returns (policy_loss, value_loss) as detached tensors."""
+def optimize(network, scaler, opt, batch, sync_gradients=True, bucket=None):
+    """One learner step (main.py:76-98).  Returns (policy_loss, value_loss) as detached tensors.
+    bucket: a parallel.GradientBucket over `network` -- the gradients then live in one flat buffer that is zeroed, accumulated
+    into, all-reduced and read by the optimiser in place (what `run` uses when there are several ranks)."""
     cuda = next(network.parameters()).is_cuda
     with torch.autocast('cuda', enabled=cuda):
         policy_loss, value_loss = losses(network, batch)
         loss = policy_loss + value_loss
-    opt.zero_grad()
+    if bucket is not None:
+        bucket.zero()
+    else:
+        opt.zero_grad()
     scaler.scale(loss).backward()
     if sync_gradients:
-        parallel.allreduce_gradients(network)
+        if bucket is not None:
+            bucket.allreduce()
+        else:
+            parallel.allreduce_gradients(network)
     scaler.step(opt)
     scaler.update()
     return policy_loss.detach(), value_loss.detach()
 
 
-def run(worlds, network, n_steps, nodes=64, c_puct=1 / 16, lr=1e-3, buffer_len=64, graph=False, inference=None, on_step=None):
+def run(worlds, network, n_steps, nodes=64, c_puct=1 / 16, lr=1e-3, buffer_len=64, graph=False, inference=None, on_step=None, timings=None):
     """main.py:147-200 minus run bookkeeping.  `worlds` is this rank's env shard.  Returns the final worlds.
     inference: None (the module under autocast, as the reference), 'torch' or 'fused' (networks.Inference plans; their
     f16 weights are refreshed from the module at the start of every move, so optimiser steps are seen).
@@ -77,6 +92,12 @@ def run(worlds, network, n_steps, nodes=64, c_puct=1 / 16, lr=1e-3, buffer_len=6
         agents.append(MCTSAgent(actor, n_nodes=nodes, c_puct=c_puct, graph=graph, **kwargs))
     opt = torch.optim.Adam(network.parameters(), lr=lr)
     scaler = torch.amp.GradScaler('cuda', enabled=(dev.type == 'cuda'))
+    # several ranks: the gradients live in one flat buffer that is all-reduced where it lies (parallel.GradientBucket)
+    bucket = parallel.GradientBucket(network) if (torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1) else None
+    if timings is not None and torch.distributed.is_initialized():
+        # under the benchmark: the same code path in a one-rank group, too, every collective bracketed by device events
+        bucket = parallel.GradientBucket(network, always=True, timed=True)
+        timings['bucket'] = bucket
     idxs = [(torch.randint(buffer_len, (w.n_envs,), device=dev), torch.arange(w.n_envs, device=dev)) for w in batches]
     buffers = [[] for _ in batches]
 
@@ -100,6 +121,8 @@ def run(worlds, network, n_steps, nodes=64, c_puct=1 / 16, lr=1e-3, buffer_len=6
         for s_ in streams:
             s_.wait_stream(torch.cuda.current_stream(dev))
     for step in range(n_steps):
+        if timings is not None:
+            _sync(dev); t_play = time.perf_counter(); moves_before = sum(len(b) for b in buffers)
         while any(len(b) < buffer_len for b in buffers):
             for i in range(len(batches)):
                 if len(buffers[i]) < buffer_len:
@@ -111,9 +134,17 @@ def run(worlds, network, n_steps, nodes=64, c_puct=1 / 16, lr=1e-3, buffer_len=6
         if concurrent:
             for s_ in streams:                                  # the learner reads what the actors' streams produced ...
                 torch.cuda.current_stream(dev).wait_stream(s_)
+        if timings is not None:
+            _sync(dev)
+            timings.setdefault('selfplay_s', []).append(time.perf_counter() - t_play)
+            timings.setdefault('moves', []).append(sum(len(b) for b in buffers) - moves_before)
         for i in range(len(batches)):
+            if timings is not None:
+                _sync(dev); t0 = time.perf_counter()
             chunk, buffers[i] = as_chunk(buffers[i], batches[i].n_envs)
-            pl, vl = optimize(network, scaler, opt, chunk[idxs[i]])
+            pl, vl = optimize(network, scaler, opt, chunk[idxs[i]], bucket=bucket)
+            if timings is not None:
+                _sync(dev); timings.setdefault('learner_s', []).append(time.perf_counter() - t0)
             if on_step is not None:
                 on_step(step, pl, vl)
         if concurrent:

@@ -54,10 +54,19 @@ typedef struct {
                           2 / 4 = that many, two waves each, and the waves of an env whose descent has ended join the envs of their
                           workgroup that still go (batches of 4..8 guessed levels for exactly the long descents).  Ignored when
                           expand_waves is set */
-    int expand_help;   /* with expand_envs 2 / 4: free waves join an env only from this descent level on (default 0) */
+    int expand_help;   /* with expand_envs 2 / 4: free waves join an env only from this descent level on (low byte; default 0), up to
+                          this many waves per env (next byte; default all) */
+    int powf_libm;     /* NOT a tuning choice but a second parity target: 1 = the Newton derivative term divides by glibc's
+                          powf(bot, 2) (what the reference's own JIT build computes: no -O flag, boardlaw/cuda.py:29-45,
+                          boardlaw/mcts/cpp/cpu.cpp:60) instead of bot * bot (what g++ -O1 and up make of it; the default).  The two
+                          differ on 0.036 % of floats; results then match oracle/liboracle_powf.so / _ref/mctscuda_O0.so */
 } bl_tune_t;
 
 int bl_abi_version(void);
+
+/* powf(x, 2.0f) as glibc 2.35 on x86-64 with FMA computes it (csrc/bl_powf.h), on the device: out[i] = powf(x[i], 2).  What
+ * bl_tune_t.powf_libm puts under the Newton derivative term; exported so that tests can pin it to the host libm. */
+int bl_powf2(const float* x, float* out, long n, bl_stream_t stream);
 const char* bl_strerror(int code);
 
 /* pi = expf(logit) for every binary16 bit pattern, computed by the host libm -- the function the reference's CPU

@@ -135,6 +135,75 @@ print('rccl ok')
     assert r.returncode == 0 and 'rccl ok' in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
 
 
+@pytest.mark.gpu
+def test_qrange_sync_through_rccl_inside_a_search():
+    """MCTS(qrange_sync=parallel.allreduce_qrange) -- the opt-in that makes N shards normalise q over ALL envs like one device
+    (boardlaw/mcts/cpp/cuda.cu:101-105) -- with the collective going through RCCL itself, once per simulation, eagerly AND inside a
+    captured move (a one-rank group: the pool's boxes have one GPU): every output equals the unsynchronised search's bit for bit
+    (MAX over one rank is the identity), the generator ends at the same offset, and the cost per simulation is printed."""
+    import subprocess, sys
+    code = '''
+import os, sys, time, torch, torch.distributed as dist
+sys.path.insert(0, %r)
+from boardlaw_amd import networks, parallel
+from boardlaw_amd.hex import Hex
+from boardlaw_amd.mcts import MCTSAgent, MoveRng
+os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT='29543')
+dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))
+torch.manual_seed(0)
+worlds = Hex.initial(1024, 9)
+net = networks.Inference(networks.FCModel(worlds.obs_space, worlds.action_space, 256, 2).cuda(), fused=True)
+calls = [0]
+def sync(state):
+    calls[0] += 1
+    return parallel.allreduce_qrange(state)
+outs, times = {}, {}
+for name, kw in (('plain', {}), ('synced', {'qrange_sync': sync})):
+    for graph in (False, True):
+        agent = MCTSAgent(net, n_nodes=32, graph=graph, rng=MoveRng(), **kw)
+        torch.manual_seed(5)
+        w = worlds
+        if graph:
+            agent.play(w); torch.manual_seed(5)          # capture consumes the generator: reseed
+        res = []
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(4):
+            d, w, t = agent.play(w)
+            res.append(d)
+        torch.cuda.synchronize(); times[name, graph] = (time.perf_counter() - t0) / 4
+        outs[name, graph] = (res, torch.cuda.default_generators[0].get_offset())
+assert calls[0] >= 31 * 4
+for graph in (False, True):
+    (a, oa), (b, ob) = outs['plain', graph], outs['synced', graph]
+    assert oa == ob
+    for da, db in zip(a, b):
+        for k in ('logits', 'prior', 'v', 'actions', 'n_leaves', 'n_sims'):
+            x, y = da[k], db[k]
+            if x.dtype == torch.half: x, y = x.view(torch.int16), y.view(torch.int16)
+            assert torch.equal(x, y), (graph, k)
+print('qrange sync ok: us per simulation added by the collective: eager %%.1f, captured %%.1f' %% (
+      1e6 * (times['synced', False] - times['plain', False]) / 31, 1e6 * (times['synced', True] - times['plain', True]) / 31))
+dist.destroy_process_group()
+''' % ROOT
+    r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and 'qrange sync ok' in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
+    print(r.stdout.strip().splitlines()[-1])
+
+
+@pytest.mark.gpu
+def test_train_bench_one_rank_rccl():
+    """tools/train_bench.py (config 4's launcher) at world size 1 over the nccl backend, on a reduced shape: self-play with captured
+    moves and the fused inference plan, learner steps through the persistent gradient bucket, the all-reduce timed by device events."""
+    import json, subprocess, sys
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK')}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'tools', 'train_bench.py'), '--steps', '2', '--envs', '256', '--boardsize', '9', '--nodes', '32',
+                          '--width', '256', '--depth', '2', '--buffer', '3'], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith('{')][-1])
+    assert d['n_gpus'] == 1 and d['ranks_seen'] == 1 and d['backend'] == 'nccl' and d['weights_identical_over_ranks']
+    assert len(d['learner_step_ms']) == 2 and len(d['allreduce_ms']) == 2 and d['moves'] >= 4 and d['sims_per_sec_whole_job'] > 0
+
+
 def test_arena_sweep_fans_out_over_worker_processes():
     """tools/arena_sweep.py (config 5's sweep, one job per board size on a pool of workers -- arena/neural.py:257-274's fan-out):
     the dry run plays real matches with deterministic agents on CPU worlds in two worker processes and reports one JSON line."""

@@ -64,7 +64,7 @@ def _free_port():
     s = socket.socket(); s.bind(('127.0.0.1', 0)); p = s.getsockname()[1]; s.close(); return p
 
 
-def _worker(rank, world, port, out):
+def _worker(rank, world, port, out, bucketed=False):
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
     import sys
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -75,17 +75,26 @@ def _worker(rank, world, port, out):
     shard = full[parallel.shard(64, rank, world)]
     opt = torch.optim.Adam(net.parameters(), lr=1e-2)
     scaler = torch.amp.GradScaler('cuda', enabled=False)
-    training.optimize(net, scaler, opt, shard)
+    bucket = parallel.GradientBucket(net) if bucketed else None
+    training.optimize(net, scaler, opt, shard, bucket=bucket)
+    if bucketed:
+        # a second step through the same bucket: the views survive a step (bucket.zero(), not opt.zero_grad())
+        assert bucket.intact()
+        training.optimize(net, scaler, opt, shard, bucket=bucket)
+        assert bucket.intact()
     out.put((rank, torch.cat([p.detach().flatten() for p in net.parameters()]).numpy()))
     torch.distributed.destroy_process_group()
 
 
-def test_two_rank_gradient_allreduce_equals_full_batch_step():
+@pytest.mark.parametrize('bucketed', [False, True])
+def test_two_rank_gradient_allreduce_equals_full_batch_step(bucketed):
+    """bucketed: parallel.GradientBucket -- the gradients as views of one persistent flat buffer, all-reduced in place (what
+    training.run uses with several ranks) -- against the same full-batch step(s) in one process."""
     from boardlaw_amd import training
     world, port = 2, _free_port()
     ctx = mp.get_context('spawn')
     out = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, out)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, out, bucketed)) for r in range(world)]
     for p in procs:
         p.start()
     res = dict(out.get(timeout=120) for _ in range(world))
@@ -93,9 +102,26 @@ def test_two_rank_gradient_allreduce_equals_full_batch_step():
         p.join(60); assert p.exitcode == 0
     net, full = _toy_net(0), _toy_batch(64, 1)
     opt = torch.optim.Adam(net.parameters(), lr=1e-2)
-    training.optimize(net, torch.amp.GradScaler('cuda', enabled=False), opt, full, sync_gradients=False)
+    for _ in range(2 if bucketed else 1):
+        training.optimize(net, torch.amp.GradScaler('cuda', enabled=False), opt, full, sync_gradients=False)
     want = torch.cat([p.detach().flatten() for p in net.parameters()]).numpy()
-    assert np.allclose(res[0], res[1], atol=0) and np.allclose(res[0], want, atol=1e-6)
+    assert np.allclose(res[0], res[1], atol=0) and np.allclose(res[0], want, atol=2e-6)
+
+
+def test_train_bench_two_ranks_dry_run():
+    """tools/train_bench.py --gpus 2 (config 4's launcher: one process per GPU, the learner's gradients through ONE all-reduce of the
+    persistent bucket) as a CPU dry run over gloo: the self-spawn, the rendezvous, the bucket all-reduce (checked against the known
+    mean inside the script) and the single JSON line with both ranks seen."""
+    import json, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK')}
+    out = subprocess.run([sys.executable, os.path.join(root, 'tools', 'train_bench.py'), '--gpus', '2', '--steps', '3'], env={**env, 'TRAIN_DRY': '1'},
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 2 and d['ranks_seen'] == 2 and d['per_rank_values'] == [1.0, 2.0] and d['dry_run']
 
 
 def test_as_chunk_shapes():
