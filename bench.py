@@ -69,7 +69,12 @@ def tree_statistics(worlds, net, nodes):
     """d (policy evaluations / descent), k (expanded-child lookups / descent), Newton iterations / evaluation: measured
     by the counting variant of the kernel on one untimed search."""
     from boardlaw_amd.mcts import MCTS
-    m = MCTS(worlds, n_nodes=nodes, count=True)
+    powf = os.environ.pop('BL_POWF_LIBM', None)      # the counting build exists for the default parity target only (same statistics)
+    try:
+        m = MCTS(worlds, n_nodes=nodes, count=True)
+    finally:
+        if powf is not None:
+            os.environ['BL_POWF_LIBM'] = powf
     m.initialize(net)
     for _ in range(nodes - 1):
         m.simulate(net)
@@ -315,6 +320,26 @@ def main():
         finally:
             del os.environ['BL_FOLD_SAFE']
 
+    value_powf_libm = None
+    if world == 1 and not args.eager and not args.no_fold_safe and 'BL_POWF_LIBM' not in os.environ:
+        # the second parity target -- the reference as its own JIT build computes (no -O flag: glibc's powf(bot, 2) under the Newton
+        # derivative term instead of bot*bot; bl_tune_t.powf_libm, csrc/bl_powf.h): what the exact mode costs
+        os.environ['BL_POWF_LIBM'] = '1'
+        try:
+            powf_agent = MCTSAgent(agent.network, n_nodes=NODES, graph=True, rng=MoveRng())
+            w6 = worlds
+            for _ in range(1 + min(args.warmup, 2)):
+                w6 = powf_agent.play(w6)[1]
+            barrier()
+            t5 = time.perf_counter()
+            for _ in range(args.steps):
+                w6 = powf_agent.play(w6)[1]
+            barrier()
+            value_powf_libm = args.envs * NODES * args.steps / (time.perf_counter() - t5)
+            del powf_agent, w6
+        finally:
+            del os.environ['BL_POWF_LIBM']
+
     two_actors = None
     if world == 1 and not args.eager and not args.no_two_actors and default_shape:
         # NOT the metric (its configuration is ONE 4096-env search per GPU): a second, independent config-2 search resident on
@@ -425,7 +450,9 @@ def main():
                                                   'reference\'s run: on tests/golden/search_9x9_w512.npz >= 95 % of the envs pick the reference\'s first action and >= 60 % have '
                                                   'identical root visit counts (tests/test_reference_fixtures.py)',
                        'parity_target': 'reference cpu.cpp as g++ -O1 and up compiles it (powf(bot, 2) folded to bot*bot); the reference\'s own JIT build passes no -O flag and calls '
-                                        'libm powf, which differs from bot*bot on 0.036 % of floats (oracle/liboracle_powf.so keeps that variant; the HIP path does not)',
+                                        'libm powf, which differs from bot*bot on 0.036 % of floats: that target is bl_tune_t.powf_libm (BL_POWF_LIBM=1; glibc 2.35\'s powf restated in '
+                                        'csrc/bl_powf.h, equal to the host libm on all 2^32 floats; checker oracle/liboracle_powf.so) -- value_powf_libm is its rate',
+                       'value_powf_libm': value_powf_libm,   # the same moves in the reference's-own-build mode (bl_tune_t.powf_libm; ISA-padded fold)
                        'fold_fast': bool(_native.fold_fast(torch.device('cuda', local))),
                        'value_fold_safe': value_fold_safe,   # the ISA-padded fold (two wait states per dependent DPP step): what a device that fails bl_selftest() runs
                        'value_reference_rng_protocol': value,          # the headline IS on the reference's stream (MoveRng above)

@@ -92,6 +92,9 @@ __device__ __forceinline__ int bperm_i(int src_lane, int v) { return __builtin_a
 // RMAX: blocks of 32 kept actions a node can have (ceil(A / 32));  KT: registers of node slots (ceil(T / 64));
 // NW: waves per env.
 //
+// POWF: the reference's own JIT build (bl_tune_t.powf_libm): the derivative term divides by glibc's powf(bot, 2) -- its own instantiation
+// (ISA-padded fold, two waves per env), so that the default kernels carry none of its f64 code.
+//
 // NW > 1 -- speculative batches.  What policy() computes at a node (the Newton solve and the drawn edge: the uniform is
 // rands[b, node]) depends on that node alone, not on how the descent got there.  So the NW waves of an env (one per
 // SIMD) evaluate, at the same time, the current node and its most likely continuation u1 = fav[u0], u2 = fav[u1], ...
@@ -103,7 +106,7 @@ __device__ __forceinline__ int bperm_i(int src_lane, int v) { return __builtin_a
 // descent to get deep (`deep_thresh` 0 / 3 / 5 / 8: 57 / 62 / 65 / 69 us): a wasted guess costs nothing that matters,
 // the kernel is bound by the latency of its longest descent, not by VALU throughput.
 // ------------------------------------------------------------------------------------------------------------------
-template <int RMAX, int KT, bool FAST, bool COUNT, int NW>
+template <int RMAX, int KT, bool FAST, bool COUNT, int NW, bool POWF = false>
 // 8 waves per SIMD for boards up to 9x9: 4096 envs x 2 waves are the chip's 8192 wave slots, and without the bound the
 // kernel's 106 SGPRs admit 6 (a quarter of the envs would start only when others have finished)
 __global__ void __launch_bounds__(BL_WAVE * NW, (RMAX <= 3 ? 8 : 4)) sim_expand2_kernel(Search s, int sim, const uint16_t* rands, int16_t* leaves_out,
@@ -245,7 +248,7 @@ __global__ void __launch_bounds__(BL_WAVE * NW, (RMAX <= 3 ? 8 : 4)) sim_expand2
                     const bool isS = lowhalf != ((r & 1) != 0);
                     const float bot = alpha - q[r];
                     num[r] = isS ? top[r] : -top[r];
-                    den[r] = isS ? bot : g_denominator(bot, s.powf_libm);
+                    den[r] = isS ? bot : (POWF ? g_denominator(bot, 1) : bot * bot);
                 }
                 ieee_div_n<RR>(num, den, quo);
 #pragma unroll
@@ -285,7 +288,7 @@ __global__ void __launch_bounds__(BL_WAVE * NW, (RMAX <= 3 ? 8 : 4)) sim_expand2
                     const bool isS = lowhalf != ((r & 1) != 0);
                     const float bot = alpha - q[r];
                     const float num = isS ? top[r] : -top[r];
-                    const float den = isS ? bot : g_denominator(bot, s.powf_libm);
+                    const float den = isS ? bot : (POWF ? g_denominator(bot, 1) : bot * bot);
                     term[r] = in[r] ? num / den : 0.f;                    // prob(a), cuda.cu:23-25, resp. its derivative term
                 }
             }
@@ -544,7 +547,7 @@ __device__ __forceinline__ void evaluate_node(const Search& s, const long envbas
                 const bool isS = lowhalf != ((r & 1) != 0);
                 const float bot = alpha - q[r];
                 num[r] = isS ? top[r] : -top[r];
-                den[r] = isS ? bot : g_denominator(bot, s.powf_libm);
+                den[r] = isS ? bot : bot * bot;
             }
             ieee_div_n<RR>(num, den, quo);
 #pragma unroll
@@ -982,7 +985,7 @@ __global__ void __launch_bounds__(BL_WAVE) sim_expand3_kernel(Search s, int sim,
                 for (int r = 0; r < RR; r++) {
                     const float bot = alpha - q[r];
                     num[r] = isS ? top[r] : -top[r];
-                    den[r] = isS ? bot : g_denominator(bot, s.powf_libm);
+                    den[r] = isS ? bot : bot * bot;
                 }
                 ieee_div_n<RR>(num, den, quo);                            // prob(a), cuda.cu:23-25, resp. its derivative term
 #pragma unroll
@@ -1194,7 +1197,7 @@ int bl_expand2_launch(const Search& ss, int sim, const void* rands, int16_t* lea
                       unsigned long long* counters, int fast, int waves, int deep_thresh, int envs, int help_thresh, hipStream_t stream) {
     const int A = ss.S * ss.S, T = ss.T;
     if (!ss.cpi || !ss.cca || !ss.nk || A > 384 || T > 256) return BL_ETOOBIG;
-    if ((envs == 2 || envs == 4) && ss.fav && A <= 192 && T <= 64 && !counters) {
+    if ((envs == 2 || envs == 4) && ss.fav && A <= 192 && T <= 64 && !counters && !ss.powf_libm) {
         // envs per workgroup, two waves each, finished envs' waves help the ones still going (sim_expand4_kernel)
         const dim3 grid4((ss.B + envs - 1) / envs), block4(64 * 2 * envs);
         const size_t lds4 = (size_t)al16(A) * envs;
@@ -1207,7 +1210,7 @@ int bl_expand2_launch(const Search& ss, int sim, const void* rands, int16_t* lea
 #undef BLX4
         return hipGetLastError() == hipSuccess ? BL_OK : BL_ELAUNCH;
     }
-    if (waves == 21 && ss.fav && A <= 96 && T <= 64 && !counters) {
+    if (waves == 21 && ss.fav && A <= 96 && T <= 64 && !counters && !ss.powf_libm) {
         // two nodes per wave (sim_expand3_kernel)
         const dim3 grid3(ss.B), block3(64);
         const size_t lds3 = (size_t)al16(A);
@@ -1218,7 +1221,21 @@ int bl_expand2_launch(const Search& ss, int sim, const void* rands, int16_t* lea
 #undef BLX3
         return hipGetLastError() == hipSuccess ? BL_OK : BL_ELAUNCH;
     }
-    if ((waves != 4 && waves != 2) || !ss.fav) waves = 1;
+    if ((waves != 4 && waves != 2) || !ss.fav) waves = 1;     // (eight waves per env: measured in round 4, slower at every batch size -- profiles/r04_waves8.txt)
+    if (ss.powf_libm && counters) return BL_EINVAL;      // the counting build exists for the default target only
+    if (ss.powf_libm) {
+        // the second parity target (bl_tune_t.powf_libm): one instantiation per shape -- ISA-padded fold, two waves per env (one without fav)
+        const int needp = (A + 31) / 32;
+        const dim3 gridp(ss.B);
+        const size_t ldsp = (size_t)al16(A);
+#define BLXP(R_, K_, W_) hipLaunchKernelGGL((sim_expand2_kernel<R_, K_, false, false, W_, true>), gridp, dim3(64 * W_), ldsp, stream, ss, sim, \
+                                            (const uint16_t*)rands, leaves, obs, valid, leaf_seats, (unsigned long long*)nullptr, deep_thresh)
+#define BLXPK(R_) { if (T <= 64) { if (ss.fav) BLXP(R_, 1, 2); else BLXP(R_, 1, 1); } else { if (ss.fav) BLXP(R_, 4, 2); else BLXP(R_, 4, 1); } }
+        if (needp <= 1) BLXPK(1) else if (needp <= 2) BLXPK(2) else if (needp <= 3) BLXPK(3) else if (needp <= 6) BLXPK(6) else BLXPK(12)
+#undef BLXPK
+#undef BLXP
+        return hipGetLastError() == hipSuccess ? BL_OK : BL_ELAUNCH;
+    }
     const int need = (A + 31) / 32;
     const int rmax = need <= 1 ? 1 : need <= 2 ? 2 : need <= 3 ? 3 : need <= 6 ? 6 : 12;
     const int kt = T <= 64 ? 1 : 4;

@@ -109,6 +109,12 @@ __device__ __forceinline__ float readlane_f(float v, int lane) {
 // consume pieces s = 0..3.  (Row-major weights made every load instruction touch 32 cache lines: 97 us per forward.)
 // A fragments use the same k assignment from LDS.  K % 64 == 0.
 template <int NT, int RD> struct Ring { half8 b[RD][NT][4]; };      // RD k blocks of weight fragments: RD - 1 in flight, one in use
+// BL_MLP_RING_FULL (round 4, measured neutral, off): fill all RD slots at a layer boundary, see gemm_prefetch
+#ifdef BL_MLP_RING_FULL
+#define BLM_RING_FULL 1
+#else
+#define BLM_RING_FULL 0
+#endif
 
 template <int NT>
 __device__ __forceinline__ void ring_load(half8 (&b)[NT][4], const uint16_t* Wp, int KB, int tile0, int ntiles_valid, int kb) {
@@ -126,8 +132,12 @@ __device__ __forceinline__ void ring_load(half8 (&b)[NT][4], const uint16_t* Wp,
 template <int NT, int RD>
 __device__ __forceinline__ void gemm_prefetch(Ring<NT, RD>& rg, const uint16_t* Wp, int K, int tile0, int ntiles_valid, int rot = 0) {
     const int KB = K >> 6;
+    // Every call site sits between two GEMMs (before the staging barrier, before an epilogue): no ring slot is in use then, so
+    // all RD of them COULD take a block -- the slot the last GEMM step has just released would travel under the epilogue too,
+    // instead of being requested by the next GEMM's first step.  Built in round 4 (-DBL_MLP_RING_FULL), bit-exact, 238 VGPRs, and
+    // within the noise of RD - 1 (profiles/r04_mlp_ring.txt): the stream is at the L1's rate, not short of requests.  Off.
 #pragma unroll
-    for (int d = 0; d < RD - 1; d++)
+    for (int d = 0; d < RD - 1 + BLM_RING_FULL; d++)
         if (d == 0 || d < KB) ring_load<NT>(rg.b[d], Wp, KB, tile0, ntiles_valid, rot + d < KB ? rot + d : rot + d - KB);      // KB >= 1
 }
 
@@ -165,7 +175,7 @@ __device__ __forceinline__ void gemm_run(Ring<NT, RD>& rg, const uint16_t* in, i
         for (int i = 0; i < KBC; i++) {
             // (sched_barrier: left to itself the scheduler sinks each load to just before its use to save registers, which
             // is the opposite of a prefetch)
-            if (i + RD - 1 < KBC) ring_load<NT>(rg.b[(i + RD - 1) % RD], Wp, KBC, tile0, NT, blk(i + RD - 1));
+            if (i + RD - 1 < KBC && !(BLM_RING_FULL && i == 0)) ring_load<NT>(rg.b[(i + RD - 1) % RD], Wp, KBC, tile0, NT, blk(i + RD - 1));   // block RD - 1 came with the prefetch
             __builtin_amdgcn_sched_barrier(0);
             compute(rg.b[i % RD], blk(i));
             __builtin_amdgcn_sched_barrier(0);
@@ -176,7 +186,8 @@ __device__ __forceinline__ void gemm_run(Ring<NT, RD>& rg, const uint16_t* in, i
 #pragma unroll
         for (int d = 0; d < RD; d++) {
             if (i + d < KB) {
-                if (i + d + RD - 1 < KB) ring_load<NT>(rg.b[(d + RD - 1) % RD], Wp, KB, tile0, ntiles_valid, blk(i + d + RD - 1));
+                if (i + d + RD - 1 < KB && !(BLM_RING_FULL && i == 0 && d == 0))       // block RD - 1 came with the prefetch
+                    ring_load<NT>(rg.b[(d + RD - 1) % RD], Wp, KB, tile0, ntiles_valid, blk(i + d + RD - 1));
                 compute(rg.b[d], blk(i + d));
                 if (i == 0 && d == 0 && own_first) __syncthreads();
             }

@@ -26,5 +26,8 @@ def pytest_collection_modifyitems(config, items):
 
 @pytest.fixture(scope='session')
 def oracle():
+    # BL_POWF_LIBM=1 switches BOTH sides to the reference's own JIT build (no -O flag: libm powf under the Newton derivative term,
+    # boardlaw/cuda.py:29-45, mcts/cpp/cpu.cpp:60): the product through bl_tune_t.powf_libm (_native.tune reads the variable), the
+    # checker through oracle/liboracle_powf.so, which calls the host libm itself
     import oracle_lib
-    return oracle_lib.load()
+    return oracle_lib.load('_powf' if os.environ.get('BL_POWF_LIBM') == '1' else '')
