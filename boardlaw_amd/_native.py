@@ -11,6 +11,7 @@ import torch
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIBPATH = os.path.join(HERE, 'libboardlaw_amd.so')
 QRANGE_WORDS = 4096
+BL_OK, BL_EINVAL, BL_ETOOBIG, BL_ELAUNCH = 0, -1, -2, -3
 
 _vp, _i = ctypes.c_void_p, ctypes.c_int
 
@@ -49,6 +50,7 @@ SYMBOLS = {
     'bl_rezero_relu_f16': (_i, [_vp, _vp, _vp, _vp, _vp, ctypes.c_long, _vp]),
     'bl_mlp_forward_f16': (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     'bl_mlp_layers_f16': (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    'bl_mlp_layers_persist_f16': (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
     'bl_root_mlp_f32': (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     'bl_sim_infer_finish': (_i, [ctypes.POINTER(Search), _i] + [_vp] * 11 + [_i] * 4 + [_vp]),
     'bl_sim_root': (_i, [ctypes.POINTER(Search), _i, _vp, _vp, _vp, _vp]),

@@ -701,37 +701,38 @@ struct LayerArgs {
     int M;
     int ncol;                                                     // column groups of 128 features per row tile (set by the launcher)
     int xcd;                                                      // 1: row tile r on XCD r % 8 (set by the launcher)
+    int sc1_out;                                                  // 1: Y is read by other workgroups of the SAME launch (layers_persist_kernel)
 };
 
-// RD - 1 k blocks of 4 KiB in flight per wave; KBC = Kpad / 64 when it is one of the body widths' (the block loop is then
-// straight-line code and every MFMA waits for exactly its fragment -- with ONE wave per SIMD there is nobody to hide a
-// drained weight stream behind, unlike in mlp_kernel), 0 = any (the intake).
-template <int RD, int KBC>
-__global__ void __launch_bounds__(256) layer_kernel(LayerArgs a) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    uint16_t* R = (uint16_t*)smem;
+struct NoWait { static constexpr bool early = false; __device__ __forceinline__ void operator()() const {} };
+
+// 8-byte relaxed agent-scope atomics = `global_load/store_dwordx2 ... sc1`: the loads bypass the CU's L1, the stores go through to
+// memory -- a valid payload form for a cross-workgroup hand-off WITHOUT fences (MI355X_MICROARCH.md, inter-workgroup visibility:
+// "8-B agent atomics both sides"); an agent-scope release/acquire pair instead writes back / invalidates whole caches (3.4-8 us per
+// hand-off, and polling with acquire loads cuts the chip's bandwidth -- the first version of the kernel below: 447 us per forward).
+__device__ __forceinline__ uint2 ld_sc1(const void* p) {
+    const unsigned long long v = __hip_atomic_load((const unsigned long long*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return make_uint2((uint32_t)v, (uint32_t)(v >> 32));
+}
+__device__ __forceinline__ void st_sc1(void* p, uint2 v) {
+    __hip_atomic_store((unsigned long long*)p, (unsigned long long)v.x | ((unsigned long long)v.y << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// One workgroup's share of one Linear: rows 32 * rowtile .., features 128 * colgroup ..  Contains one workgroup barrier; waves
+// without a tile and lanes whose row is beyond M leave after it.
+template <int RD, int KBC, typename PRE>
+__device__ __forceinline__ void layer_body(const LayerArgs& a, const int rowtile, const int colgroup, uint16_t* R, PRE pre) {
     const int ld = a.Kpad + 8;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    // Which 32 rows x 128 features this workgroup takes.  Workgroup i runs on XCD i % 8.  All column groups of a row tile are placed
-    // on ONE XCD (row tile r on XCD r % 8), and the same way in every layer's launch: the rows a workgroup stages were written by
-    // workgroups of its own XCD in the previous launch and are still in that XCD's L2, instead of coming from the seven others
-    // through the fabric.  Placement is a speed matter only.
-    // Measured (13x13, 1024x8, tools/ab_layers.sh): 1024 rows 94.6 -> 80.5 us per forward; 256 rows 71.3 -> 78.5 us -- there
-    // every XCD then streams ALL the weights for its one row tile, where the plain mapping (column group x on XCD x, any row
-    // tile) lets an XCD fetch only its eighth of them: the launcher picks by the row count.
-    int rowtile, colgroup;
-    if (a.xcd) {
-        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-        rowtile = xcd + 8 * (slot / a.ncol); colgroup = slot % a.ncol;
-        if (rowtile * 32 >= a.M) return;
-    } else {
-        rowtile = blockIdx.x / a.ncol; colgroup = blockIdx.x % a.ncol;
-    }
     const int row0 = rowtile * 32, tile = colgroup * 4 + wave, ntiles = a.N >> 5;
     const int brow = lane & 31, hf = lane >> 5;
     Ring<1, RD> rg;
     float16v acc[1];
     const bool active = tile < ntiles;
+    // EARLY (the persistent kernel): the first weight fragments are requested BEFORE `pre` waits for the previous layer -- weights
+    // do not depend on it -- and the input rows after
+    constexpr bool EARLY = PRE::early;      // also: this layer's rows come from / go to other workgroups of THIS launch (sc1 payload)
+    if (EARLY) { if (active) gemm_prefetch<1, RD>(rg, a.Wp, a.Kpad, tile, 1); pre(); }
     // the input rows first, then the first weight fragments (vmcnt retires in order: see mlp_kernel)
     const half2v z2 = {(f16)0.f, (f16)0.f};
     if ((a.ldx & 7) == 0 && (a.Kvalid & 7) == 0) {
@@ -746,9 +747,12 @@ __global__ void __launch_bounds__(256) layer_kernel(LayerArgs a) {
 #pragma unroll
         for (int i = 0; i < NB; i++) {
             v[i] = make_uint4(0, 0, 0, 0);
-            if (rok && 64 * i + 8 * j < a.Kvalid) v[i] = *(const uint4*)(src + 64 * i);
+            if (rok && 64 * i + 8 * j < a.Kvalid) {
+                if constexpr (EARLY) { const uint2 lo = ld_sc1(src + 64 * i), hi = ld_sc1(src + 64 * i + 4); v[i] = make_uint4(lo.x, lo.y, hi.x, hi.y); }
+                else v[i] = *(const uint4*)(src + 64 * i);
+            }
         }
-        if (active) gemm_prefetch<1, RD>(rg, a.Wp, a.Kpad, tile, 1);
+        if (!EARLY && active) gemm_prefetch<1, RD>(rg, a.Wp, a.Kpad, tile, 1);
 #pragma unroll
         for (int i = 0; i < NB; i++) {
             if (64 * i < a.Kpad) {
@@ -780,7 +784,7 @@ __global__ void __launch_bounds__(256) layer_kernel(LayerArgs a) {
                 if (64 * k < wvalid) { if (rok && w < wvalid) v[i][k] = src[w]; }
             }
         }
-        if (active) gemm_prefetch<1, RD>(rg, a.Wp, a.Kpad, tile, 1);      // behind the rows' loads: vmcnt retires in order
+        if (!EARLY && active) gemm_prefetch<1, RD>(rg, a.Wp, a.Kpad, tile, 1);      // behind the rows' loads: vmcnt retires in order
 #pragma unroll
         for (int i = 0; i < 8; i++) {
             const int r = wave * 8 + i;
@@ -805,7 +809,7 @@ __global__ void __launch_bounds__(256) layer_kernel(LayerArgs a) {
     for (int g = 0; g < 4; g++) {
         biasr[g] = *(const uint2*)(a.bias + n0 + 8 * g + 4 * hf);
         xold[g] = make_uint2(0, 0);
-        if (a.Xres && rowok) xold[g] = *(const uint2*)(a.Xres + grow * a.N + n0 + 8 * g + 4 * hf);
+        if (a.Xres && rowok) { if constexpr (EARLY) xold[g] = ld_sc1(a.Xres + grow * a.N + n0 + 8 * g + 4 * hf); else xold[g] = *(const uint2*)(a.Xres + grow * a.N + n0 + 8 * g + 4 * hf); }
     }
     half2v al2 = {(f16)0.f, (f16)0.f};
     if (a.Xres) { const f16 al = (f16)((const __attribute__((address_space(4))) float*)a.alpha)[0]; al2[0] = al; al2[1] = al; }
@@ -817,7 +821,7 @@ __global__ void __launch_bounds__(256) layer_kernel(LayerArgs a) {
         const float a4[4] = {acc[0][4 * g], acc[0][4 * g + 1], acc[0][4 * g + 2], acc[0][4 * g + 3]};
         uint2 xo, ro;
         rezero4(a4, biasr[g], xold[g], al2, a.Xres == nullptr, xo, ro);
-        if (a.Y) *(uint2*)(a.Y + grow * a.ldy + f0) = xo;
+        if (a.Y) { if (a.sc1_out) st_sc1(a.Y + grow * a.ldy + f0, xo); else *(uint2*)(a.Y + grow * a.ldy + f0) = xo; }
         else {
             const uint16_t o[4] = {(uint16_t)xo.x, (uint16_t)(xo.x >> 16), (uint16_t)xo.y, (uint16_t)(xo.y >> 16)};
 #pragma unroll
@@ -825,6 +829,122 @@ __global__ void __launch_bounds__(256) layer_kernel(LayerArgs a) {
                 if (f0 + j < a.NH - 1) a.policy[grow * (a.NH - 1) + f0 + j] = o[j];
                 else if (f0 + j == a.NH - 1) a.value[grow] = o[j];
             }
+        }
+    }
+}
+
+// RD - 1 k blocks of 4 KiB in flight per wave; KBC = Kpad / 64 when it is one of the body widths' (the block loop is then
+// straight-line code and every MFMA waits for exactly its fragment -- with ONE wave per SIMD there is nobody to hide a
+// drained weight stream behind, unlike in mlp_kernel), 0 = any (the intake).
+template <int RD, int KBC>
+__global__ void __launch_bounds__(256) layer_kernel(LayerArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    uint16_t* R = (uint16_t*)smem;
+    // Which 32 rows x 128 features this workgroup takes.  Workgroup i runs on XCD i % 8.  All column groups of a row tile are placed
+    // on ONE XCD (row tile r on XCD r % 8), and the same way in every layer's launch: the rows a workgroup stages were written by
+    // workgroups of its own XCD in the previous launch and are still in that XCD's L2, instead of coming from the seven others
+    // through the fabric.  Placement is a speed matter only.
+    // Measured (13x13, 1024x8, tools/ab_layers.sh): 1024 rows 94.6 -> 80.5 us per forward; 256 rows 71.3 -> 78.5 us -- there
+    // every XCD then streams ALL the weights for its one row tile, where the plain mapping (column group x on XCD x, any row
+    // tile) lets an XCD fetch only its eighth of them: the launcher picks by the row count.
+    int rowtile, colgroup;
+    if (a.xcd) {
+        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+        rowtile = xcd + 8 * (slot / a.ncol); colgroup = slot % a.ncol;
+        if (rowtile * 32 >= a.M) return;
+    } else {
+        rowtile = blockIdx.x / a.ncol; colgroup = blockIdx.x % a.ncol;
+    }
+    layer_body<RD, KBC>(a, rowtile, colgroup, R, NoWait{});
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// All Linears of the forward in ONE launch (round 4): the launch-per-Linear plan above sits on a floor of ~7.5 us per layer
+// whatever the batch (a dependent launch boundary, a cold trip for the rows, the first weight fragments' trip), ten times per
+// forward at 1024x8.  But a row tile's next layer depends on THAT ROW TILE's previous layer only: the eight workgroups that own
+// its column groups (all on one XCD, see layer_kernel).  So a workgroup keeps its (row tile, column group) through all layers,
+// and between two layers it
+//   * requests the next layer's first weight fragments (they depend on nothing),
+//   * publishes its rows -- every wave a release fence at agent scope, a workgroup barrier, one atomic add on the row tile's
+//     counter for that layer -- and waits until the counter says all column groups of the row tile have published (one lane
+//     polls with acquire loads, then the workgroup barrier: the CU's vector L1 is invalidated by the acquire, plain loads of
+//     the rows follow; /opt/skills/guides recipe G16),
+//   * stages the rows and runs the layer as before.
+// Waiting only for one's own row tile is also what makes buffer re-use safe: layer l + 1 overwrites the rows layer l read, and
+// only after every reader of that row tile has finished layer l.
+// Co-residency: a workgroup spins for peers of its row tile, so those must get CUs.  The grid is at most 256 workgroups of 4
+// waves and 66 KiB of LDS (two fit a CU), the peers of a row tile lie within 64 consecutive workgroup indices, and every spin is
+// BOUNDED: if a wait runs out (another process hogging the chip) the kernel raises `error` in the counter block and finishes
+// with whatever it has -- wrong results the host can see (networks.Inference checks the word), never a hung GPU.
+// The last workgroup to finish zeroes the counters, so a captured forward replays without a reset launch.
+// ------------------------------------------------------------------------------------------------------------------
+#define BLM_MAX_LAYERS 12
+#define BLM_SPIN_LIMIT (1 << 21)
+struct PersistArgs {
+    LayerArgs layer[BLM_MAX_LAYERS];
+    int nlayers, rowtiles, ncol;      // ncol: column groups of the body layers = the grid's (the heads use fewer)
+    int* counters;                    // [rowtiles][nlayers] arrivals + one word: workgroups finished
+    int* error;                       // set to 1 when a bounded wait ran out
+    int xcd;
+};
+
+__global__ void __launch_bounds__(256) zero_words_kernel(int* p, int n) {
+    for (int i = threadIdx.x; i < n; i += 256) p[i] = 0;
+}
+
+// layers_persist_kernel's wait between two layers: all column groups of the row tile have published the previous layer.  ONE lane
+// polls with relaxed loads (acquire loads in a poll loop invalidate the L1 every time), then the workgroup barrier.
+struct RowTileWait {
+    static constexpr bool early = true;
+    const int* counter; int want; int* error;
+    __device__ __forceinline__ void operator()() const {
+        if (threadIdx.x == 0) {
+            int polls = 0;
+            while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
+                if (++polls > BLM_SPIN_LIMIT) { __hip_atomic_store(error, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+                __builtin_amdgcn_s_sleep(1);
+            }
+        }
+        __syncthreads();
+    }
+};
+
+template <int RDB, int KBCB>
+__global__ void __launch_bounds__(256) layers_persist_kernel(const PersistArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    uint16_t* R = (uint16_t*)smem;
+    const int tid = threadIdx.x;
+    int rowtile, colgroup;
+    if (p.xcd) {
+        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+        rowtile = xcd + 8 * (slot / p.ncol); colgroup = slot % p.ncol;
+    } else {
+        rowtile = blockIdx.x / p.ncol; colgroup = blockIdx.x % p.ncol;
+    }
+    int* done = p.counters + (long)p.rowtiles * p.nlayers;
+    if (rowtile < p.rowtiles) {
+        int* mine = p.counters + (long)rowtile * p.nlayers;
+        for (int l = 0; l < p.nlayers; l++) {
+            const LayerArgs& a = p.layer[l];
+            const RowTileWait wait{mine + (l > 0 ? l - 1 : 0), l > 0 ? p.layer[l - 1].ncol : 0, p.error};
+            if (colgroup < a.ncol) {
+                if (l == 0) layer_body<3, 0>(a, rowtile, colgroup, R, NoWait{});
+                else layer_body<RDB, KBCB>(a, rowtile, colgroup, R, wait);
+            }                                                         // (a workgroup beyond the layer's column groups -- the heads' -- has nothing to do)
+            if (l + 1 < p.nlayers) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's sc1 stores have been acknowledged ...
+                __syncthreads();                                      // ... and so have the other waves' (and nobody still reads R)
+                if (tid == 0 && colgroup < a.ncol) __hip_atomic_fetch_add(mine + l, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    }
+    // the last workgroup out zeroes the counters for the next forward
+    __syncthreads();
+    if (tid == 0) {
+        const int total = gridDim.x;
+        if (__hip_atomic_fetch_add(done, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == total - 1) {
+            for (long i = 0; i < (long)p.rowtiles * p.nlayers; i++) p.counters[i] = 0;
+            __hip_atomic_store(done, 0, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
 }
@@ -931,6 +1051,49 @@ extern "C" int bl_mlp_layers_f16(const void* obs, int M, int K0, const void* w0,
     launch(LayerArgs{buf[D & 1], W, W, W, 0, (const uint16_t*)wh, (const uint16_t*)bh, NHpad, nullptr, nullptr, nullptr, 0,
                      (uint16_t*)policy_out, (uint16_t*)value_out, NH, M}, W);
     if (rc != BL_OK) return rc;
+    return hipGetLastError() == hipSuccess ? BL_OK : BL_ELAUNCH;
+}
+
+extern "C" int bl_mlp_layers_persist_f16(const void* obs, int M, int K0, const void* w0, const void* b0, const void* wb,
+                                         const void* bb, const float* alphas, const void* wh, const void* bh, int W, int D,
+                                         int K0pad, int NH, int NHpad, void* scratch, int* counters, int zero_first, int* error,
+                                         void* policy_out, void* value_out, bl_stream_t stream) {
+    using namespace blmlp;
+    if (!policy_out || !value_out || !scratch || !counters || !error) return BL_EINVAL;
+    if (int rc = mlp_check(obs, M, K0, w0, b0, wb, bb, alphas, wh, bh, W, D, K0pad, NH, NHpad)) return rc;
+    if ((K0 & 1) != 0) return BL_EINVAL;
+    if (D + 2 > BLM_MAX_LAYERS || (W != 256 && W != 512 && W != 768 && W != 1024)) return BL_ETOOBIG;
+    PersistArgs p;
+    p.nlayers = D + 2; p.rowtiles = (M + 31) / 32; p.ncol = W / 128; p.counters = counters; p.error = error; p.xcd = M >= 512;
+    const unsigned grid = p.xcd ? 8u * ((p.rowtiles + 7) / 8) * p.ncol : (unsigned)p.rowtiles * p.ncol;
+    if (grid > 256) return BL_ETOOBIG;          // every workgroup must find a CU while its row tile's peers run: see layers_persist_kernel
+    uint16_t* buf[2] = {(uint16_t*)scratch, (uint16_t*)scratch + (size_t)M * W};
+    auto set = [&](int i, LayerArgs a) { a.ncol = (a.N / 32 + 3) / 4; a.xcd = p.xcd; a.sc1_out = a.Y != nullptr; p.layer[i] = a; };
+    set(0, LayerArgs{(const uint16_t*)obs, K0, K0, K0pad, 0, (const uint16_t*)w0, (const uint16_t*)b0, W, nullptr, nullptr, buf[0], W, nullptr, nullptr, 0, M});
+    for (int l = 0; l < D; l++)
+        set(1 + l, LayerArgs{buf[l & 1], W, W, W, 1, (const uint16_t*)wb + (size_t)l * W * W, (const uint16_t*)bb + (size_t)l * W, W,
+                             buf[l & 1], alphas + l, buf[(l + 1) & 1], W, nullptr, nullptr, 0, M});
+    set(D + 1, LayerArgs{buf[D & 1], W, W, W, 0, (const uint16_t*)wh, (const uint16_t*)bh, NHpad, nullptr, nullptr, nullptr, 0,
+                         (uint16_t*)policy_out, (uint16_t*)value_out, NH, M});
+    const int kmax = K0pad > W ? K0pad : W;
+    const size_t lds = (size_t)32 * (kmax + 8) * 2;
+    hipStream_t hs = (hipStream_t)stream;
+    // fresh memory: the counters are zeroed by a launch of their own (a kernel, not a memset node: those replay only once in a captured
+    // graph on this ROCm); the kernel leaves them zero, so a caller that keeps the block passes zero_first = 0 from the second call on
+    if (zero_first) hipLaunchKernelGGL(zero_words_kernel, dim3(1), dim3(256), 0, hs, counters, p.rowtiles * p.nlayers + 1);
+#define BL_PERSIST_LAUNCH(RD, KBC)                                                                                               \
+    {                                                                                                                            \
+        static size_t raised[64];                                                                                                \
+        if (!bl_raise_lds_limit((const void*)layers_persist_kernel<RD, KBC>, lds, raised)) return BL_ELAUNCH;                     \
+        hipLaunchKernelGGL((layers_persist_kernel<RD, KBC>), dim3(grid), dim3(256), lds, hs, p);                                 \
+    }
+    switch (W) {
+        case 1024: BL_PERSIST_LAUNCH(8, 16) break;
+        case 768: BL_PERSIST_LAUNCH(8, 12) break;
+        case 512: BL_PERSIST_LAUNCH(6, 8) break;
+        default: BL_PERSIST_LAUNCH(4, 4) break;
+    }
+#undef BL_PERSIST_LAUNCH
     return hipGetLastError() == hipSuccess ? BL_OK : BL_ELAUNCH;
 }
 

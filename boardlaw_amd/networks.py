@@ -84,6 +84,10 @@ class Inference:
     FUSED_ALWAYS_BYTES = 6 << 20
     FUSED_MIN_TILES = 96
     LAYERS_PLAN = True      # below that: bl_mlp_layers_f16 (False: torch's GEMMs + bl_rezero_relu_f16, bit-identical to autocast)
+    # ... as ONE launch where the grid fits the chip (bl_mlp_layers_persist_f16): bit-identical, measured in round 4 and SLOWER at every
+    # shape (1024x8 on 1024 rows: 91.9 against 80.8 us; profiles/r04_layers_persist.txt) -- a hand-off between workgroups through
+    # memory costs what a launch boundary costs.  Off.
+    PERSIST_PLAN = False
 
     def __init__(self, model, fused=False):
         """fused=True additionally runs all Linears as ONE MFMA kernel (bl_mlp_forward_f16) when the width is a multiple
@@ -93,6 +97,7 @@ class Inference:
         self.fused = fused
         self._static = None
         self._packed = None
+        self._persist = {}          # bl_mlp_layers_persist_f16's error word per device
         self._root_heads = None
         self._root_packed = None
         self._stamped = None
@@ -160,6 +165,8 @@ class Inference:
                 dst.copy_(src)
             for dst, src in zip(self._static[1], alphas):
                 dst.copy_(src)
+            if srcs[0].is_cuda and not torch.cuda.is_current_stream_capturing():
+                self._persist_error(srcs[0].device)          # exists before any capture
             if self.fused and self._fusable():
                 # layout of bl_mlp_forward_f16: zero-padded intake, stacked blocks, policy+value head stacked
                 w = self._static[0]
@@ -258,6 +265,20 @@ class Inference:
                 return out[:, :-1], out[:, -1]
             return F.linear(x, m.policy.core.weight, m.policy.core.bias), F.linear(x, m.value.core.weight, m.value.core.bias).squeeze(-1)
 
+    def _persist_error(self, device):
+        """The word bl_mlp_layers_persist_f16 raises when one of its bounded waits ran out (made at refresh(), outside any capture)."""
+        key = device.index if device.index is not None else torch.cuda.current_device()
+        if key not in self._persist:
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError('Inference: call refresh() (or one eager forward) before capturing')
+            self._persist[key] = torch.zeros((1,), dtype=torch.int32, device=device)
+        return self._persist[key]
+
+    def persist_error(self):
+        """True if a bounded wait of bl_mlp_layers_persist_f16 ever ran out (its workgroups' peers were kept off the chip): the forwards
+        of that call were invalid.  Synchronises."""
+        return any(int(c.item()) != 0 for c in self._persist.values())
+
     def prefers_fused(self, rows):
         """Whether the one-kernel plan is the faster one for a batch of `rows` (see FUSED_ALWAYS_BYTES)."""
         if not (self.fused and self._packed is not None):
@@ -309,9 +330,21 @@ class Inference:
             value = torch.empty((M,), dtype=torch.half, device=x0.device)
             scratch = torch.empty((2, M, W), dtype=torch.half, device=x0.device)
             with torch.cuda.device(x0.device):
-                _native.check(L.bl_mlp_layers_f16(x0.data_ptr(), M, K0, pk['w0'].data_ptr(), w[1].data_ptr(), pk['wb'].data_ptr(),
-                                                  pk['bb'].data_ptr(), pk['al'].data_ptr(), pk['wh'].data_ptr(), pk['bh'].data_ptr(),
-                                                  W, D, K0pad, NH, NHpad, scratch.data_ptr(), policy.data_ptr(), value.data_ptr(), st))
+                rc = _native.BL_ETOOBIG
+                if self.PERSIST_PLAN:
+                    # all Linears in one launch, workgroups synchronising per row tile (bl_mlp_layers_persist_f16): grids up to 256
+                    # workgroups.  The counter block is this call's own (like `scratch`: from the caching allocator, or from a capture's
+                    # pool -- two actors sharing this plan on two streams never share one) and is zeroed by the call
+                    counters = torch.empty((-(-M // 32) * (D + 2) + 1,), dtype=torch.int32, device=x0.device)
+                    rc = L.bl_mlp_layers_persist_f16(x0.data_ptr(), M, K0, pk['w0'].data_ptr(), w[1].data_ptr(), pk['wb'].data_ptr(),
+                                                     pk['bb'].data_ptr(), pk['al'].data_ptr(), pk['wh'].data_ptr(), pk['bh'].data_ptr(),
+                                                     W, D, K0pad, NH, NHpad, scratch.data_ptr(), counters.data_ptr(), 1,
+                                                     self._persist_error(x0.device).data_ptr(), policy.data_ptr(), value.data_ptr(), st)
+                if rc == _native.BL_ETOOBIG:
+                    rc = L.bl_mlp_layers_f16(x0.data_ptr(), M, K0, pk['w0'].data_ptr(), w[1].data_ptr(), pk['wb'].data_ptr(),
+                                             pk['bb'].data_ptr(), pk['al'].data_ptr(), pk['wh'].data_ptr(), pk['bh'].data_ptr(),
+                                             W, D, K0pad, NH, NHpad, scratch.data_ptr(), policy.data_ptr(), value.data_ptr(), st)
+                _native.check(rc)
             return policy, value
         x = F.linear(x0, w[0], w[1])
         r = F.relu(x)

@@ -248,6 +248,19 @@ int bl_mlp_layers_f16(const void* obs /*f16 (M,K0)*/, int M, int K0, const void*
                       int NHpad, void* scratch /*f16 (2,M,W)*/, void* policy_out /*f16 (M,NH-1)*/, void* value_out /*f16 (M)*/,
                       bl_stream_t stream);
 
+/* The same forward as bl_mlp_layers_f16 in ONE launch (round 4): a workgroup keeps its (32 rows, 128 features) share through
+ * all layers and waits, between two layers, only for the workgroups that own the other column groups of ITS row tile (release /
+ * acquire on a counter per row tile and layer in `counters`).  Bit-identical to bl_mlp_layers_f16.  For grids of at most 256
+ * workgroups (1024 rows at W = 1024, 2048 at W = 512, ...): BL_ETOOBIG otherwise -- the caller then launches per Linear.
+ * counters: int32 device array of ceil(M/32) * (D + 2) + 1 words that must be ZERO when the kernel starts and is zero again when it
+ * ends; zero_first = 1 zeroes it with a launch of its own first (for fresh memory: e.g. a block allocated per call).
+ * error: one int32 device word the caller zeroes once; the kernel sets it to 1 when a bounded wait ran out (another process kept the
+ * workgroups' peers off the chip): the outputs of that call are invalid. */
+int bl_mlp_layers_persist_f16(const void* obs /*f16 (M,K0)*/, int M, int K0, const void* w0, const void* b0, const void* wb,
+                              const void* bb, const float* alphas, const void* wh, const void* bh, int W, int D, int K0pad,
+                              int NH, int NHpad, void* scratch /*f16 (2,M,W)*/, int32_t* counters, int zero_first, int32_t* error,
+                              void* policy_out, void* value_out, bl_stream_t stream);
+
 /* bl_mlp_forward_f16 followed by bl_sim_finish as ONE launch: the workgroup that took 32 leaves through the network also
  * applies the heads to them, stores logits/v, backs up along the recorded paths and publishes the next q range; what
  * that step reads from the tree is requested at the start of the kernel and arrives under the GEMMs.  Same results as

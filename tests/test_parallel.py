@@ -187,7 +187,7 @@ dist.destroy_process_group()
 ''' % ROOT
     r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and 'qrange sync ok' in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
-    print(r.stdout.strip().splitlines()[-1])
+    print([l for l in r.stdout.splitlines() if 'qrange sync ok' in l][-1])
 
 
 @pytest.mark.gpu

@@ -23,6 +23,9 @@ def timed(f, n=200):
     return a.elapsed_time(b) / (n // 10 * 10) * 1e3
 res = {}
 plan.FUSED_ALWAYS_BYTES = 1 << 40; res['one kernel'] = timed(lambda: plan.raw(w))
-plan.FUSED_ALWAYS_BYTES = 0; plan.FUSED_MIN_TILES = 1 << 30; res['launch per Linear'] = timed(lambda: plan.raw(w))
+plan.FUSED_ALWAYS_BYTES = 0; plan.FUSED_MIN_TILES = 1 << 30
+plan.PERSIST_PLAN = True; res['all Linears in one launch (row-tile sync)'] = timed(lambda: plan.raw(w))
+plan.PERSIST_PLAN = False; res['launch per Linear'] = timed(lambda: plan.raw(w))
 plan.LAYERS_PLAN = False; res['library GEMMs'] = timed(lambda: plan.raw(w))
+assert not plan.persist_error()
 print(f'{S}x{S} board, {width}x{depth}, {B} rows (us per forward, inside a captured graph): ' + ', '.join(f'{k} {v:.1f}' for k, v in res.items()))

@@ -69,7 +69,7 @@ def dry_run(args):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=2, help='learner steps (each after `buffer` more moves of self-play... the first after filling the buffer)')
+    ap.add_argument('--steps', type=int, default=3, help='learner steps (each after `buffer` more moves of self-play... the first after filling the buffer)')
     ap.add_argument('--envs', type=int, default=1024, help='envs per rank (config 4: 8192 over 8 GPUs)')
     ap.add_argument('--boardsize', type=int, default=13)
     ap.add_argument('--nodes', type=int, default=256)
@@ -114,7 +114,9 @@ def main():
             'metric': 'train_bench', 'n_gpus': world, 'ranks_seen': seen, 'per_rank_sims_per_sec': per_rank, 'backend': torch.distributed.get_backend(),
             'config': {'workload': f'{args.boardsize}x{args.boardsize} Hex, {args.envs} envs/rank x {args.nodes} sims/move, FCModel {args.width}x{args.depth}, '
                                    f'learner step every {args.buffer} moves' + (' (BASELINE config 4 per-GPU shape)' if (args.boardsize, args.envs, args.nodes, args.width, args.depth) == (13, 1024, 256, 1024, 8) else '')},
-            'selfplay_ms_per_move': 1e3 * float(sum(timings['selfplay_s'])) / max(moves, 1), 'moves': moves,
+            # by learner step: the first carries the moves' graph capture and warm-up, the later ones are the steady rate
+            'selfplay_ms_per_move_by_step': [round(1e3 * t / max(m, 1), 3) for t, m in zip(timings['selfplay_s'], timings['moves'])],
+            'selfplay_ms_per_move': round(1e3 * timings['selfplay_s'][-1] / max(timings['moves'][-1], 1), 3), 'moves': moves,
             'learner_step_ms': [round(1e3 * x, 3) for x in timings['learner_s']],
             'allreduce_ms': [round(x, 3) for x in ar], 'bucket_mb': round(timings['bucket'].flat.numel() * 4 / 2**20, 2),
             'sims_per_sec_whole_job': args.envs * args.nodes * moves * world / elapsed, 'elapsed_s': elapsed,
