@@ -16,7 +16,6 @@ Two execution paths produce identical arrays:
     host sync, `sim` kept on the host, capturable in a HIP graph.
 """
 import ctypes
-import os
 
 import numpy as np
 import torch
@@ -83,14 +82,6 @@ class MoveRng(TorchRng):
             _native.check(_native.lib().bl_rand_block(block.data_ptr(), self.expected, x.numel(), threads, loops, seed, offset, intragraph,
                                                       captured, tri, _native.stream(x.device)))
         return block
-
-    def prefetch(self, x):
-        """Draws the announced block NOW (MCTS.initialize calls this right after the Dirichlet draw, on a side stream beside the root
-        evaluation): the generator is consumed in the reference's order either way -- Dirichlet, then the descents' uniforms -- only the
-        launch no longer waits for the first descent."""
-        if self.block is None and self.expected > 0 and x.is_cuda and x.dtype == torch.half:
-            self.block, self.i = self._draw_block(x), 0
-        return self.block
 
     def rand_like(self, x):
         if self.block is None and self.expected > 0 and x.is_cuda and x.dtype == torch.half:
@@ -170,7 +161,7 @@ class LeafWorlds:
 class MCTS:
 
     def __init__(self, world, n_nodes=64, c_puct=1 / 16, noise_eps=.25, alpha_scale=10, fused=None, rng=None,
-                 count=False, obs_half=False, qrange_sync=None, fuse_finish=True, n_active=None, lazy=False, fork_draws=None):
+                 count=False, obs_half=False, qrange_sync=None, fuse_finish=True, n_active=None, lazy=False):
         """c_puct high: concentrates on prior; c_puct low: concentrates on value (mcts/__init__.py:29-33).
         n_active (fused path): a one-element int32 DEVICE tensor -- only the first n_active[0] envs of `world` are searched, the
         rest sit the simulations out and add nothing to the q-range (bl_search_t.n_active): what lets one captured move of B
@@ -191,8 +182,6 @@ class MCTS:
         self.qrange_sync = qrange_sync
         # network forward + finish as one launch (bl_sim_infer_finish) when the network offers its packed weights
         self.fuse_finish = fuse_finish
-        # the move's random draws on a side stream beside the root evaluation (fused path; BL_FORK_DRAWS=0 switches it off)
-        self.fork_draws = (os.environ.get('BL_FORK_DRAWS', '1') != '0') if fork_draws is None else fork_draws
         # the fused kernels hard-code two-seat Hex; its one-player variants (hex.Solitaire) take the generic path
         self.fused = (isinstance(world, hexmod.Hex) and world.n_seats == 2) if fused is None else fused
         if self.fused and not isinstance(world, hexmod.Hex):
@@ -270,36 +259,14 @@ class MCTS:
                 and type(getattr(network.model, 'policy', None)).__name__ == 'MaskedOutput'):
             # the network's Linears in fp32, then heads + dirichlet noise + store as ONE launch (bl_sim_plant_root)
             assert self.sim == 0
-            alpha = _constant(self.n_actions, self.alpha_scale / self.n_actions, self.device, torch.float)
-
-            def draws():
-                # the move's random draws, in the reference's order of generator use: the Dirichlet (mcts/__init__.py:16-18), then
-                # the block of the descents' uniforms (MoveRng; TorchRng draws those call by call later)
-                if hasattr(self.rng, 'gamma'):
-                    d = self.rng.gamma(alpha, (self.n_envs,)).float().contiguous()
-                else:
-                    d = self.rng.dirichlet(alpha, (self.n_envs,)).float().contiguous()
-                block = self.rng.prefetch(self.decisions.logits[:, :, 0]) if hasattr(self.rng, 'prefetch') else None
-                return d, block
-
-            if self.fork_draws:
-                # ... issued on a side stream BESIDE the root evaluation (neither depends on the other; the root's fp32 MFMA kernel
-                # leaves the integer pipes to the Philox rounds): forked branches of one captured graph do run side by side
-                main = torch.cuda.current_stream(self.device)
-                side = _side_stream(self.device, main)
-                side.wait_stream(main)
-                with torch.cuda.stream(side):
-                    draw, block = draws()
-                policy_raw, value_raw = network.root_raw(world)
-                main.wait_stream(side)
-                for t in (draw, block):
-                    if t is not None:
-                        t.record_stream(main)              # allocated on the side stream, used (and freed) on this one
-            else:
-                policy_raw, value_raw = network.root_raw(world)
-                draw, _ = draws()
+            policy_raw, value_raw = network.root_raw(world)
             policy_raw, value_raw = policy_raw.float().contiguous(), value_raw.float().contiguous()
             valid = world.valid.contiguous()
+            alpha = _constant(self.n_actions, self.alpha_scale / self.n_actions, self.device, torch.float)
+            if hasattr(self.rng, 'gamma'):
+                draw = self.rng.gamma(alpha, (self.n_envs,)).float().contiguous()
+            else:
+                draw = self.rng.dirichlet(alpha, (self.n_envs,)).float().contiguous()  # mcts/__init__.py:16-18
             with torch.cuda.device(self.device):
                 _native.check(_native.lib().bl_sim_plant_root(ctypes.byref(self._search), policy_raw.data_ptr(), value_raw.data_ptr(),
                                                               valid.data_ptr(), world.seats.int().contiguous().data_ptr(),
@@ -474,16 +441,6 @@ def mcts(worlds, network, **kwargs):
 
 
 _constants = {}
-_side_streams = {}
-
-
-def _side_stream(device, main):
-    """One side stream per (device, stream it forks from): two actors searching on their own streams do not meet on a shared one."""
-    key = (device.index if device.index is not None else torch.cuda.current_device(), main.cuda_stream)
-    if key not in _side_streams:
-        _side_streams[key] = torch.cuda.Stream(device=device)
-    return _side_streams[key]
-
 
 
 def _constant(n, value, device, dtype=torch.long):
