@@ -603,7 +603,7 @@ enum { EV_GO = 0,       // leader -> members: batch number << 8 | positions of t
        EV_NREQ,         // tickets taken by joining waves (position = 2 + ticket)
        EV_NLEV, EV_GOING, EV_B, EV_CPUCT, EV_WORDS = 8 };
 #define EV_FIN 0x7fffffff
-#define BLX_POLL_LIMIT (1 << 20)     // a wave never waits for ever: a protocol error ends in wrong results (which the parity tests see), not in a hung GPU
+#define BLX_POLL_LIMIT (1 << 20)     // a wave never waits for ever: a protocol error TRAPS (the launch fails loudly at the next sync), it neither hangs the GPU nor passes wrong results on
 
 __device__ __forceinline__ int lds_peek(const int* p) {     // one broadcast LDS read, wave-uniform
     return __builtin_amdgcn_readfirstlane(__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
@@ -729,7 +729,7 @@ __global__ void __launch_bounds__(BL_WAVE * 2 * NE, (RMAX <= 3 ? 8 : 4)) sim_exp
                     int a_k = ra, c_k = rc, s_k = rs;
                     if (k > 0) {
                         int polls = 0;
-                        while (lds_peek(&res[e][k][3]) != seq && ++polls < BLX_POLL_LIMIT) __builtin_amdgcn_s_sleep(1);
+                        while (lds_peek(&res[e][k][3]) != seq) { if (++polls >= BLX_POLL_LIMIT) __builtin_trap(); __builtin_amdgcn_s_sleep(1); }
                         lds_order();
                         a_k = lds_peek(&res[e][k][0]); c_k = lds_peek(&res[e][k][1]); s_k = lds_peek(&res[e][k][2]);
                     }
@@ -855,6 +855,7 @@ __global__ void __launch_bounds__(BL_WAVE * 2 * NE, (RMAX <= 3 ? 8 : 4)) sim_exp
             if (pos >= W) att = -1;                   // cannot happen (a workgroup has W - 2 waves besides an env's own two)
         }
     }
+    __builtin_trap();                                 // the poll budget ran out: a protocol error
 }
 
 // ------------------------------------------------------------------------------------------------------------------
