@@ -1,7 +1,16 @@
 """bench.py -- MCTS simulations/sec on 9x9 Hex, 4096 envs x 64 sims per move (BASELINE.json config 2), per GPU.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config {1,2,4,5}]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+--config picks another BASELINE.json configuration (the metric is quoted on 2, the default; 3 is 2 on every GPU, i.e. --gpus 8):
+  1  5x5, 64 envs x 16 sims, FCModel 16x4 (the reference's CPU-runnable plumbing case)
+  4  13x13, 1024 envs per GPU x 256 sims, FCModel 1024x8, actor + learner: a step is one self-play move of the shard plus one
+     learner step on a 64-move buffer (boardlaw/main.py:147-200 at steady state), gradients averaged over ranks by one RCCL
+     all-reduce of a flat bucket (parallel.GradientBucket)
+  5  the arena sweep: boards 3..11, 2048 games each between two 64-sim 512x4 search agents through arena.evaluate's masked calls
+     (boardlaw/arena/common.py:75-106); a step is one sweep over the nine board sizes
+each with the same one-line JSON (roofline of bl_sim_expand at that shape, cpu_baseline on a bounded sample of that shape).
 
 A "step" is one self-play move of the whole batch: MCTSAgent(worlds) -- root evaluation + 63 simulations per env, i.e.
 T = 64 network evaluations per env (SURVEY 8d counts the root as a simulation) -- followed by worlds.step(actions).
@@ -96,13 +105,13 @@ def total_bytes_per_sim(A, S, T, d, k):
     return d * (4 * A + 5) + 4 * k + (T + 1) / 2 * (2 * S + 2) + (d + 1) * (6 * S + 7) + 13 * A + 6 * S + 19
 
 
-def cpu_baseline(seconds_budget=24.0):
+def cpu_baseline(seconds_budget=24.0, envs=ENVS, single_envs=256):
     """The same search on this box's host cores with the C oracle's kernels (tests/cpu_driver.py): every physical core,
     one process each, plus a single process and the -O0 build for ns/descent."""
     sys.path.insert(0, os.path.join(ROOT, 'tests'))
     try:
         from cpu_driver import run_cpu_baseline
-        return run_cpu_baseline(BOARD, NODES, WIDTH, DEPTH, ENVS, seconds_budget)
+        return run_cpu_baseline(BOARD, NODES, WIDTH, DEPTH, envs, seconds_budget, single_envs=single_envs)
     except Exception as e:  # pragma: no cover
         return {'value': None, 'unit': 'sims/s', 'cores': 0, 'kind': 'port', 'sample': f'unavailable: {type(e).__name__}: {e}'}
 
@@ -147,6 +156,201 @@ def measure_traffic(kernel='sim_expand', timeout=240):
     return (2 * f_kb + w_kb) * 1024, (f'measured in this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes of `bench.py --steps 2 '
                                        f'--warmup 1 --timed-only`, mean over {n_f} / {n_w} launches: FETCH_SIZE {f_kb:.1f} KB (x2: gfx950 counts coalesced 128-B requests '
                                        f'at 64 B), WRITE_SIZE {w_kb:.1f} KB')
+
+
+def rate_of(agent, worlds, steps, warmup, barrier):
+    """sims/s of `steps` self-play moves by `agent` from `worlds` (captured on the first call, then 1-2 warm-up moves)."""
+    w = worlds
+    for _ in range(1 + min(warmup, 2)):
+        w = agent.play(w)[1]
+    barrier()
+    t = time.perf_counter()
+    for _ in range(steps):
+        w = agent.play(w)[1]
+    barrier()
+    return worlds.n_envs * agent.kwargs['n_nodes'] * steps / (time.perf_counter() - t)
+
+
+def hex_kernels(envs=(4096, 1 << 20), steps=1024, boardsize=11):
+    """The reference's step / observe micro-benchmarks (boardlaw/hex/tests.py:186-215: 4096 envs x 1024 calls of `cuda.step` on one
+    fixed action set resp. `cuda.observe`, after 1024 random moves) for the two board kernels of the path that really are HBM-bound,
+    through the C ABI: bl_hex_step (the reference's in-place kernel), bl_hex_world_step (Hex.step as one launch: board in, board
+    out, seats, rewards, terminal) and bl_hex_observe_valid (observe + valid mask).  samples/s as the reference prints them, and
+    GB/s of algorithmic bytes against the 8 TB/s peak: step 2 S^2 + 16 B per env (board read + written in place, seat, action,
+    rewards), world_step 2 S^2 + 25, observe_valid 10 S^2 + 4 (board + seat read, 8 S^2 of f32 planes + S^2 of mask written).
+    4096 envs is the reference's size -- one 0.5 MB board batch, launch-latency-bound; 2^20 envs is where the kernels meet HBM.
+    Timed two ways: the reference's way (a host loop of launches, then a synchronise) and as one captured graph of the same
+    launches under HIP events (device time only)."""
+    from boardlaw_amd import _native
+    from boardlaw_amd.hex import Hex
+    L, S = _native.lib(), boardsize
+    out = {'boardsize': S, 'calls': steps, 'harness': 'boardlaw/hex/tests.py:186-215', 'peak_GBs': HBM_PEAK_GBS, 'sizes': {}}
+    gen = torch.Generator(device='cuda'); gen.manual_seed(7)
+    for B in envs:
+        worlds = Hex.initial(B, S)
+        for _ in range(S * S // 3):                           # mid-game boards; the reference plays 1024 random moves
+            valid = worlds.valid
+            worlds, _ = worlds.step((torch.rand(valid.shape, device='cuda', generator=gen) * valid).argmax(-1), check=False)
+        valid = worlds.valid
+        actions = (torch.rand(valid.shape, device='cuda', generator=gen) * valid).argmax(-1).int().contiguous()
+        board, seats = worlds.board.contiguous(), worlds.seats.int().contiguous()
+        scratch = board.clone()
+        board_out, seats_out = torch.empty_like(board), torch.empty_like(seats)
+        rewards = torch.empty((B, 2), dtype=torch.float, device='cuda'); terminal = torch.empty((B,), dtype=torch.bool, device='cuda')
+        obs = torch.empty((B, S, S, 2), dtype=torch.float, device='cuda'); vmask = torch.empty((B, S * S), dtype=torch.bool, device='cuda')
+        st = lambda: _native.stream(board.device)
+        calls = {
+            'bl_hex_step': (lambda: L.bl_hex_step(scratch.data_ptr(), seats.data_ptr(), actions.data_ptr(), rewards.data_ptr(), B, S, st()), 2 * S * S + 16),
+            'bl_hex_world_step': (lambda: L.bl_hex_world_step(board.data_ptr(), seats.data_ptr(), actions.data_ptr(), 0, board_out.data_ptr(), seats_out.data_ptr(),
+                                                                rewards.data_ptr(), terminal.data_ptr(), B, S, st()), 2 * S * S + 25),
+            'bl_hex_observe_valid': (lambda: L.bl_hex_observe_valid(board.data_ptr(), seats.data_ptr(), obs.data_ptr(), vmask.data_ptr(), B, S, st()), 10 * S * S + 4),
+        }
+        n = steps if B <= 65536 else max(16, steps // 16)
+        res = {}
+        for name, (fn, nbytes) in calls.items():
+            for _ in range(3):
+                _native.check(fn())
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(n):
+                fn()
+            torch.cuda.synchronize()
+            host_s = (time.perf_counter() - t0) / n
+            side = torch.cuda.Stream(); side.wait_stream(torch.cuda.current_stream())
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.stream(side):
+                with torch.cuda.graph(graph, stream=side):
+                    for _ in range(n):
+                        fn()
+            torch.cuda.current_stream().wait_stream(side)
+            graph.replay(); torch.cuda.synchronize()
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record(); graph.replay(); b.record(); torch.cuda.synchronize()
+            dev_s = 1e-3 * a.elapsed_time(b) / n
+            res[name] = {'samples_per_sec_host_loop': B / host_s, 'samples_per_sec_graph': B / dev_s, 'us_per_call_graph': 1e6 * dev_s,
+                         'bytes_per_env': nbytes, 'GBs': B * nbytes / dev_s / 1e9, 'frac_of_hbm_peak': B * nbytes / dev_s / 1e9 / HBM_PEAK_GBS}
+        out['sizes'][str(B)] = res
+    return out
+
+
+class Learner:
+    """Config 4's learner beside the actor (boardlaw/main.py:147-200 at steady state): a buffer of the last `buffer_len` moves,
+    one AMP Adam step per move on one random timestep per env, the gradients in one flat bucket that is all-reduced over ranks
+    in place (training.optimize + parallel.GradientBucket; RCCL on GPUs, a one-rank group included so the code path is the same)."""
+
+    def __init__(self, net, n_envs, buffer_len, device):
+        from boardlaw_amd import parallel
+        if not torch.distributed.is_initialized():         # one rank: a one-rank group, so that the collective runs and is timed
+            os.environ.setdefault('MASTER_ADDR', '127.0.0.1'); os.environ.setdefault('MASTER_PORT', '29535')
+            backend = os.environ.get('BENCH_BACKEND', 'nccl')
+            kw = {'device_id': device} if backend == 'nccl' else {}
+            torch.distributed.init_process_group(backend, rank=0, world_size=1, **kw)
+        self.net, self.buffer, self.buffer_len = net, [], buffer_len
+        self.opt = torch.optim.Adam(net.parameters(), lr=1e-3)
+        self.scaler = torch.amp.GradScaler('cuda')
+        self.bucket = parallel.GradientBucket(net, always=True, timed=True)
+        self.idxs = (torch.randint(buffer_len, (n_envs,), device=device), torch.arange(n_envs, device=device))
+        self.steps, self.n_envs = 0, n_envs
+
+    def push(self, worlds, decisions, transition):
+        from boardlaw_amd import arrdict, learning, training
+        self.buffer.append(arrdict.arrdict(worlds=worlds, decisions=decisions.half(), transitions=learning.half(transition)).detach())
+        if len(self.buffer) >= self.buffer_len:
+            chunk, self.buffer = training.as_chunk(self.buffer, self.n_envs)
+            training.optimize(self.net, self.scaler, self.opt, chunk[self.idxs], bucket=self.bucket)
+            self.bucket.events = self.bucket.events[-64:]
+            self.steps += 1
+
+
+def arena_config(args):
+    """--config 5: the arena sweep on this GPU -- for every board size 3..11 one match of 2048 games between two 64-sim 512x4 search
+    agents through arena.evaluate (seat-permuted, masked calls of a new batch size every round, argmax actions; captured moves per
+    capacity bucket).  A step is one sweep over the nine sizes; sims = env-moves x 64.  Prints the one-line JSON."""
+    from boardlaw_amd import _native, arena, networks, parallel
+    from boardlaw_amd.hex import Hex
+    from boardlaw_amd.mcts import MCTSAgent, MoveRng
+    rank, world, local = parallel.env_rank()
+    local = int(os.environ.get('BENCH_FORCE_DEVICE', local))
+    torch.cuda.set_device(local)
+    parallel.init(os.environ.get('BENCH_BACKEND', 'nccl'))
+    lib = _native.lib()
+    sizes, B, T = list(range(3, 12)), args.envs if args.envs != ENVS else 2048, args.nodes
+    pairs = {}
+    for S in sizes:
+        pair = {}
+        for i, name in enumerate(('one', 'two')):
+            torch.manual_seed(10 * rank + i)
+            w0 = Hex.initial(1, S)
+            pair[name] = MCTSAgent(networks.Inference(networks.FCModel(w0.obs_space, w0.action_space, args.width, args.depth).cuda(), fused=True),
+                                   graph=not args.eager, n_nodes=T, rng=MoveRng())
+        pairs[S] = pair
+
+    def sweep():
+        moves = games = 0
+        for S in sizes:
+            res = arena.evaluate(Hex.initial(B, S), pairs[S])
+            moves += sum(r.moves for r in res); games += sum(r.games for r in res)
+        return moves, games
+    for _ in range(max(args.warmup, 1)):
+        sweep()
+    parallel.barrier()
+    t0 = time.perf_counter()
+    moves = games = 0
+    for _ in range(args.steps):
+        m_, g_ = sweep(); moves += m_; games += g_
+    parallel.barrier()
+    elapsed = time.perf_counter() - t0
+    per_rank_values, ranks_seen = parallel.gather_over_ranks(moves * T / elapsed)
+    elapsed = parallel.max_over_ranks(elapsed)
+    moves_all, games_all = parallel.sum_over_ranks(moves), parallel.sum_over_ranks(games)
+    value = moves_all * T / elapsed
+    if rank != 0:
+        if world > 1:
+            torch.distributed.destroy_process_group()
+        return
+    # roofline: every bl_sim_expand launch of one eager 9x9 match under HIP events; algorithmic bytes per launch = the kernel's
+    # per-env figure at (A = 81, d, k measured on the match's opening position at full batch) x the envs of that masked call
+    S = 9
+    timer = TimedExpand(lib); lib.bl_sim_expand = timer
+    live = []
+    probe = {name: MCTSAgent(a.network, graph=False, n_nodes=T, rng=MoveRng()) for name, a in pairs[S].items()}
+
+    class Counting:
+        def __init__(self, agent): self.agent = agent
+        def __call__(self, w, **kw):
+            live.extend([w.n_envs] * (T - 1))
+            return self.agent(w, **kw)
+    timer.on = True
+    arena.evaluate(Hex.initial(B, S), {k: Counting(v) for k, v in probe.items()})
+    torch.cuda.synchronize(); timer.on = False
+    lib.bl_sim_expand = timer.orig
+    worlds9 = premix(Hex.initial(B, S), 4, torch.Generator(device='cuda'))
+    global BOARD, NODES
+    BOARD, NODES = S, T
+    d, k, its = tree_statistics(worlds9, pairs[S]['one'].network.model, T)
+    us = np.array([a.elapsed_time(b) * 1e3 for a, b in timer.pairs])
+    per_env = expand_bytes_per_env(S * S, 2, d, k)
+    achieved = per_env * float(np.sum(live[:len(us)])) / float(us.sum() * 1e-6) / 1e9
+    out = {'metric': 'mcts_sims_per_sec', 'value': value, 'unit': 'sims/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+           'ms_per_step': 1e3 * elapsed / args.steps, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f16', 'data': 'synthetic',
+           'per_rank_values': per_rank_values, 'ranks_seen': ranks_seen,
+           'config': {'workload': f'BASELINE config 5: arena sweep, boards 3..11, {B} games per board size between two {T}-sim FCModel {args.width}x{args.depth} search agents '
+                                  '(arena.evaluate: seat-permuted, masked variable-size calls, argmax actions); step = one sweep over the nine sizes; sims = env-moves x sims/move',
+                      'boards': sizes, 'envs_per_board': B, 'nodes': T, 'launch': 'eager' if args.eager else 'hip-graph per move and capacity bucket',
+                      'games_per_sec': games_all / elapsed, 'env_moves_per_step': moves_all / args.steps,
+                      'parallelism': f'replicas x{world} (every rank plays its own sweep; tools/arena_sweep.py fans the board sizes out over a worker pool instead)'},
+           'roofline': {'bound': 'hbm', 'kernel': 'bl::sim_expand2_kernel (bl_sim_expand)', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                        'frac': achieved / HBM_PEAK_GBS, 'traffic': None, 'kernel_us': float(us.mean()), 'launches_timed': int(len(us)),
+                        'bytes_per_env_per_launch': per_env, 'mean_envs_per_launch': float(np.mean(live[:len(us)])),
+                        'timing': 'HIP events around every bl_sim_expand launch of one eager 9x9 match (the masked calls shrink from 1024 envs as games end); '
+                                  'bytes per launch = per-env algorithmic bytes at 9x9 (d, k measured at the opening position) x the envs of that call'}}
+    if not args.no_cpu_baseline:
+        out['cpu_baseline'] = cpu_baseline(envs=B)
+        if isinstance(out['cpu_baseline'].get('sample'), str):
+            out['cpu_baseline']['sample'] = 'config 5 sample: the 9x9 share of the sweep as plain self-play -- ' + out['cpu_baseline']['sample']
+    print(json.dumps(out))
+    if world > 1:
+        torch.distributed.destroy_process_group()
 
 
 def respawn_per_gpu(args):
@@ -195,6 +399,7 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--config', type=int, default=2, choices=[1, 2, 3, 4, 5], help='BASELINE.json configuration (default 2: the metric; 3 = 2 on every GPU)')
     ap.add_argument('--envs', type=int, default=ENVS, help='envs per GPU (the metric is quoted at 4096)')
     ap.add_argument('--boardsize', type=int, default=BOARD, help='exploration only: the metric is quoted on 9x9')
     ap.add_argument('--nodes', type=int, default=NODES, help='exploration only: sims per move (metric: 64)')
@@ -209,13 +414,28 @@ def main():
     ap.add_argument('--no-two-actors', action='store_true', help='skip the two-actors-per-GPU region')
     ap.add_argument('--no-fold-safe', action='store_true', help='skip the timed region with the ISA-padded fold (value_fold_safe)')
     ap.add_argument('--no-soak', action='store_true', help='skip the 200 extra moves behind value_after_self_play_drift')
+    ap.add_argument('--no-variants', action='store_true', help='skip the torch-GEMM and fp32-leaves timed regions (value_torch_gemms, value_fp32_leaves)')
+    ap.add_argument('--no-hex-kernels', action='store_true', help='skip the step / observe micro-benchmark (hex_kernels)')
+    ap.add_argument('--no-learner', action='store_true', help='--config 4 without the learner step (self-play only)')
+    ap.add_argument('--buffer', type=int, default=64, help='--config 4: moves in the learner\'s buffer (boardlaw/main.py:150 keeps 64)')
     ap.add_argument('--eager', action='store_true', help='launch kernel by kernel instead of replaying a HIP graph per move')
     args = ap.parse_args()
     respawn_per_gpu(args)
+    shapes = {1: (5, 64, 16, 16, 4), 4: (13, 1024, 256, 1024, 8)}      # (board, envs per GPU, sims/move, width, depth) -- BASELINE.json configs
+    if args.config in shapes:
+        flags = ('boardsize', 'envs', 'nodes', 'width', 'depth')
+        for flag, preset in zip(flags, shapes[args.config]):
+            if getattr(args, flag) == ap.get_default(flag):
+                setattr(args, flag, preset)
     BOARD, NODES, WIDTH, DEPTH = args.boardsize, args.nodes, args.width, args.depth
-    default_shape = (BOARD, NODES, WIDTH, DEPTH) == (9, 64, 512, 4)
+    default_shape = (BOARD, NODES, WIDTH, DEPTH) == (9, 64, 512, 4) and args.config in (2, 3)
     if os.environ.get('BENCH_DRY') == '1':
         return dry_run(args)
+    if args.config == 5:
+        assert torch.cuda.is_available(), 'bench.py needs an MI355X; there is no CPU path'
+        if args.steps == ap.get_default('steps'):
+            args.steps, args.warmup = 3, 1                # a sweep is nine matches of 2048 games: seconds, not milliseconds
+        return arena_config(args)
 
     assert torch.cuda.is_available(), 'bench.py needs an MI355X; there is no CPU path'
     from boardlaw_amd import parallel
@@ -225,6 +445,9 @@ def main():
     # device 0 over gloo); the driver's multi-GPU runs use one device per rank and RCCL.
     local = int(os.environ.get('BENCH_FORCE_DEVICE', local))
     torch.cuda.set_device(local)
+    # one host thread per GPU issues every launch and replay: keep it on the cores of its GPU's NUMA node (stated in the line)
+    affinity_before = os.sched_getaffinity(0)
+    pinning = parallel.pin_to_numa_node(parallel.gpu_numa_node(local))
     parallel.init(os.environ.get('BENCH_BACKEND', 'nccl'))   # used only for the barrier and the max-over-ranks of the elapsed time
 
     from boardlaw_amd import _native, networks
@@ -243,9 +466,18 @@ def main():
     timer = TimedExpand(lib)
     lib.bl_sim_expand = timer
 
+    learner = None
+    if args.config == 4 and not args.no_learner:
+        learner = Learner(net, args.envs, args.buffer, torch.device('cuda', local))
+        args.warmup = max(args.warmup, args.buffer)          # the timed steps are steady state: buffer full, one learner step per move
+
     def move(w):
         # one actor step of the self-play loop (boardlaw/main.py:176-177): search + env step
-        return agent.play(w)[1]
+        if learner is None:
+            return agent.play(w)[1]
+        d, new_w, transition = agent.play(w)
+        learner.push(w, d, transition)                        # main.py:183-197: buffer, as_chunk, optimize (gradient all-reduce inside)
+        return new_w
 
     launch = 'eager' if args.eager else 'hip-graph per move'
     if not args.eager:
@@ -270,6 +502,14 @@ def main():
     # every rank's own rate and a count of the ranks, through the collective itself (RCCL on GPUs): the line proves N ranks ran
     per_rank_values, ranks_seen = parallel.gather_over_ranks(args.envs * NODES * args.steps / elapsed)
     elapsed = parallel.max_over_ranks(elapsed)
+    # what could make ONE rank slow, per rank and through the collective too: a device that failed bl_selftest() runs the ISA-padded
+    # fold (-10 %) and would set the max-over-ranks time silently; so would a rank left on the far socket
+    fold_fast_per_rank = [int(x) for x in parallel.gather_over_ranks(float(_native.fold_fast(torch.device('cuda', local))))[0]]
+    numa_per_rank = [int(x) for x in parallel.gather_over_ranks(float(-1 if pinning['numa_node'] is None else pinning['numa_node']))[0]]
+    cpus_per_rank = [int(x) for x in parallel.gather_over_ranks(float(pinning['cpus']))[0]]
+    rank_report = {'per_rank_values': per_rank_values, 'ranks_seen': ranks_seen, 'min': min(per_rank_values), 'max': max(per_rank_values),
+                   'mean': float(np.mean(per_rank_values)), 'fold_fast_per_rank': fold_fast_per_rank,
+                   'numa_node_per_rank': numa_per_rank, 'cpus_pinned_per_rank': cpus_per_rank, 'pinned': pinning['pinned']}
 
     sims_total = world * args.envs * NODES * args.steps
     value = sims_total / elapsed
@@ -278,12 +518,12 @@ def main():
         if rank == 0:
             print(json.dumps({'metric': 'mcts_sims_per_sec', 'value': value, 'unit': 'sims/s', 'n_gpus': world, 'steps': args.steps,
                               'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps, 'timed_only': True,
-                              'per_rank_values': per_rank_values, 'ranks_seen': ranks_seen}))
+                              'per_rank_values': per_rank_values, 'ranks_seen': ranks_seen, 'ranks': rank_report}))
         if world > 1:
             torch.distributed.destroy_process_group()
         return
     value_torch_rng = None
-    if world == 1 and not args.eager and not args.no_reference_rng:
+    if world == 1 and not args.eager and not args.no_reference_rng and default_shape:
         # the same moves with the reference's RNG protocol issued call by call: one rand_like (B,T) f16 per simulation
         # (cuda.cu:191) instead of MoveRng's one launch per move -- the same numbers from the same seed, 62 more launches per move
         from boardlaw_amd.mcts import TorchRng
@@ -299,8 +539,19 @@ def main():
         value_torch_rng = args.envs * NODES * args.steps / (time.perf_counter() - t1)
         del ref_agent, w2
 
+    value_torch_gemms = value_fp32_leaves = None
+    if world == 1 and not args.eager and not args.no_variants and default_shape and not args.plain_network:
+        # the network north_star names -- the Linears as PyTorch-ROCm (hipBLASLt) GEMMs, bit-identical to the module under fp16
+        # autocast (tests/test_gpu_parity.py::test_inference_plan_matches_autocast) -- instead of the hand-written MFMA kernel
+        value_torch_gemms = value if args.torch_gemms else rate_of(
+            MCTSAgent(networks.Inference(net, fused=False), n_nodes=NODES, graph=True, rng=MoveRng()), worlds, args.steps, args.warmup, barrier)
+        # the exact mode: leaves evaluated in fp32 like the reference's recorded (CPU) runs, f16 stores only -- a seeded run then IS
+        # the reference's run in most envs (tests/test_fp32_leaves.py, profiles/r05_fp32_leaves.txt)
+        value_fp32_leaves = rate_of(
+            MCTSAgent(networks.Inference(net, fused=True, precision='fp32'), n_nodes=NODES, graph=True, rng=MoveRng()), worlds, args.steps, args.warmup, barrier)
+
     value_fold_safe = None
-    if world == 1 and not args.eager and not args.no_fold_safe:
+    if world == 1 and not args.eager and not args.no_fold_safe and default_shape:
         # the same moves with the ISA-padded fold (two wait states between a VALU write and the DPP read of it; the headline runs
         # the one-wait-state fold only because bl_selftest() verified it on THIS device -- a device that fails the self-test gets
         # this rate).  BL_FOLD_SAFE is read by the host layer when a search is built, i.e. at this agent's capture.
@@ -321,7 +572,7 @@ def main():
             del os.environ['BL_FOLD_SAFE']
 
     value_powf_libm = None
-    if world == 1 and not args.eager and not args.no_fold_safe and 'BL_POWF_LIBM' not in os.environ:
+    if world == 1 and not args.eager and not args.no_fold_safe and default_shape and 'BL_POWF_LIBM' not in os.environ:
         # the second parity target -- the reference as its own JIT build computes (no -O flag: glibc's powf(bot, 2) under the Newton
         # derivative term instead of bot*bot; bl_tune_t.powf_libm, csrc/bl_powf.h): what the exact mode costs
         os.environ['BL_POWF_LIBM'] = '1'
@@ -432,10 +683,20 @@ def main():
             'metric': 'mcts_sims_per_sec', 'value': value, 'unit': 'sims/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps, 'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f16', 'data': 'synthetic',
-            'per_rank_values': per_rank_values, 'ranks_seen': ranks_seen,
+            'per_rank_values': per_rank_values, 'ranks_seen': ranks_seen, 'ranks': rank_report,
             'config': {'workload': f'{BOARD}x{BOARD} Hex, {args.envs} envs/GPU x {NODES} sims/move, FCModel {WIDTH}x{DEPTH} fp16 autocast'
-                                   + (' (BASELINE config 2)' if default_shape and args.envs == ENVS else ' (NOT the metric\'s configuration)')
-                                   + '; step = one self-play move of the batch',
+                                   + (' (BASELINE config 2)' if default_shape and args.envs == ENVS and world == 1 else
+                                      f' (BASELINE config 3: config 2 on each of {world} GPUs, self-play only)' if default_shape and args.envs == ENVS else
+                                      f' (BASELINE config {args.config}' + (', per-GPU shape' if args.config == 4 else '') + ')'
+                                      if args.config in shapes and (BOARD, args.envs, NODES, WIDTH, DEPTH) == shapes[args.config] else ' (NOT one of BASELINE.json\'s configurations)')
+                                   + ('; step = one self-play move of the batch' if learner is None else
+                                      f'; step = one self-play move of the shard + one learner step (buffer of {args.buffer} moves, AMP Adam, one flat-bucket '
+                                      'gradient all-reduce over the ranks: boardlaw/main.py:147-200 at steady state)'),
+                       'baseline_config': 3 if (args.config == 2 and world > 1) else args.config,
+                       'learner': None if learner is None else {
+                           'steps_taken': learner.steps, 'buffer_moves': args.buffer, 'bucket_mb': round(learner.bucket.flat.numel() * 4 / 2**20, 2),
+                           'allreduce_ms_mean': float(np.mean(learner.bucket.collective_ms()[-args.steps:])) if learner.bucket.events else None,
+                           'backend': torch.distributed.get_backend() if torch.distributed.is_initialized() else None},
                        'envs_per_gpu': args.envs, 'nodes': NODES, 'boardsize': BOARD, 'parallelism': f'replicas x{world}', 'launch': launch,
                        'network': ('nn.Module under fp16 autocast' if args.plain_network else 'fp16 inference plan, torch GEMMs (bit-identical to autocast)'
                                    if args.torch_gemms
@@ -452,6 +713,8 @@ def main():
                        'parity_target': 'reference cpu.cpp as g++ -O1 and up compiles it (powf(bot, 2) folded to bot*bot); the reference\'s own JIT build passes no -O flag and calls '
                                         'libm powf, which differs from bot*bot on 0.036 % of floats: that target is bl_tune_t.powf_libm (BL_POWF_LIBM=1; glibc 2.35\'s powf restated in '
                                         'csrc/bl_powf.h, equal to the host libm on all 2^32 floats; checker oracle/liboracle_powf.so) -- value_powf_libm is its rate',
+                       'value_torch_gemms': value_torch_gemms,   # the Linears as PyTorch-ROCm (hipBLASLt) GEMMs: bit-identical to the nn.Module under fp16 autocast -- the network north_star names
+                       'value_fp32_leaves': value_fp32_leaves,   # the exact mode (networks.Inference(precision='fp32')): leaves in fp32 like the reference's recorded runs; tests/test_fp32_leaves.py
                        'value_powf_libm': value_powf_libm,   # the same moves in the reference's-own-build mode (bl_tune_t.powf_libm; ISA-padded fold)
                        'fold_fast': bool(_native.fold_fast(torch.device('cuda', local))),
                        'value_fold_safe': value_fold_safe,   # the ISA-padded fold (two wait states per dependent DPP step): what a device that fails bl_selftest() runs
@@ -470,8 +733,13 @@ def main():
                          'kernel_us': kernel_us, 'bytes_per_launch': per_launch, 'launches_timed': len(timer.pairs),
                          'timing': 'HIP events around every launch ' + ('inside the timed region' if args.eager else 'in an eager re-run of the same moves right after the timed (graph-replay) region')},
         }
-        if world == 1 and not args.no_cpu_baseline and default_shape:
-            out['cpu_baseline'] = cpu_baseline()
+        if world == 1 and not args.no_hex_kernels and default_shape:
+            out['hex_kernels'] = hex_kernels()
+        if world == 1 and not args.no_cpu_baseline and (default_shape or args.config in shapes):
+            os.sched_setaffinity(0, affinity_before)          # the host baseline may use every core this container has
+            # a bounded sample of THIS configuration's search on the host cores (config 4: 64 envs per process -- one 13x13 / 256-sim /
+            # 1024x8 move of 64 envs is ~0.3 TFLOP of f32 numpy per process)
+            out['cpu_baseline'] = cpu_baseline(envs=args.envs, single_envs=256 if default_shape else min(64, args.envs))
         print(json.dumps(out))
     if world > 1:
         torch.distributed.destroy_process_group()

@@ -47,6 +47,7 @@ SYMBOLS = {
     'bl_sim_expand_counted': (_i, [ctypes.POINTER(Search), _i] + [_vp] * 6 + [_vp]),
     'bl_sim_backup': (_i, [ctypes.POINTER(Search), _i, _vp, _vp, _i, _vp, _i, _vp]),
     'bl_sim_finish': (_i, [ctypes.POINTER(Search), _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    'bl_sim_finish_f32': (_i, [ctypes.POINTER(Search), _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     'bl_rezero_relu_f16': (_i, [_vp, _vp, _vp, _vp, _vp, ctypes.c_long, _vp]),
     'bl_mlp_forward_f16': (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     'bl_mlp_layers_f16': (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),

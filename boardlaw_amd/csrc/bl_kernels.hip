@@ -782,8 +782,13 @@ __global__ void __launch_bounds__(BL_WAVE) sim_backup_kernel(Search s, int sim, 
 //            other seat.
 // tests/test_gpu_parity.py::test_finish_heads_match_torch checks both against torch bit for bit.
 // ------------------------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(BL_WAVE) sim_finish_kernel(Search s, int sim, const int16_t* leaves, const uint16_t* policy_raw,
-                                                            const uint16_t* value_raw, const uint8_t* valid,
+// RAW = uint16_t: the pre-head outputs are f16 (fp16 autocast, the reference's GPU configuration); RAW = float: they are f32
+// (bl_sim_finish_f32: the reference's CPU configuration, where autocast is a no-op and the heads run in f32 before `.half()`).
+__device__ __forceinline__ float raw2f(uint16_t x) { return h2f(x); }
+__device__ __forceinline__ float raw2f(float x) { return x; }
+template <typename RAW>
+__global__ void __launch_bounds__(BL_WAVE) sim_finish_kernel(Search s, int sim, const int16_t* leaves, const RAW* policy_raw,
+                                                            const RAW* value_raw, const uint8_t* valid,
                                                             const int32_t* leaf_seats, int W, int iters) {
     const int S = s.S, A = S * S, T = s.T;
     const int b = blockIdx.x, lane = threadIdx.x;
@@ -802,7 +807,7 @@ __global__ void __launch_bounds__(BL_WAVE) sim_finish_kernel(Search s, int sim, 
             e[it] = -INFINITY;
             if (it < iters) {
                 const int a = lane + it * W;
-                if (a < A) e[it] = valid[(long)b * A + a] ? h2f(policy_raw[(long)b * A + a]) : -INFINITY;
+                if (a < A) e[it] = valid[(long)b * A + a] ? raw2f(policy_raw[(long)b * A + a]) : -INFINITY;
                 mx = (it == 0) ? e[0] : ((mx > e[it]) ? mx : e[it]);
             }
         }
@@ -827,7 +832,7 @@ __global__ void __launch_bounds__(BL_WAVE) sim_finish_kernel(Search s, int sim, 
         if (lane == 0) s.nk[envbase + leaf] = (int16_t)count;
     }
     // ---- value head
-    const uint16_t tv = f2h(tanhf(h2f(value_raw[b])));
+    const uint16_t tv = f2h(tanhf(raw2f(value_raw[b])));
     const int mover = leaf_seats[b];
     const uint16_t vb0 = (mover == 0) ? tv : (uint16_t)(tv ^ 0x8000u), vb1 = (uint16_t)(vb0 ^ 0x8000u);
     if (lane == 0) { s.v[(envbase + leaf) * 2] = vb0; s.v[(envbase + leaf) * 2 + 1] = vb1; }
@@ -1230,7 +1235,7 @@ __global__ void __launch_bounds__(256) powf2_kernel(const float* x, float* out, 
 
 extern "C" {
 
-int bl_abi_version(void) { return 3; }
+int bl_abi_version(void) { return 4; }
 
 const char* bl_strerror(int code) {
     switch (code) {
@@ -1488,8 +1493,8 @@ int bl_selftest(bl_stream_t stream) {
     return wrong_fast;
 }
 
-int bl_sim_finish(const bl_search_t* s, int sim, const int16_t* leaves, const void* policy_raw, const void* value_raw,
-                  const uint8_t* valid, const int32_t* leaf_seats, bl_stream_t stream) {
+static int sim_finish_impl(int f32, const bl_search_t* s, int sim, const int16_t* leaves, const void* policy_raw, const void* value_raw,
+                           const uint8_t* valid, const int32_t* leaf_seats, bl_stream_t stream) {
     int rc = search_check(s);
     if (rc) return rc;
     if (!leaves || !policy_raw || !value_raw || !valid || !leaf_seats || !s->path || sim < 1 || sim >= s->T) return BL_EINVAL;
@@ -1497,9 +1502,23 @@ int bl_sim_finish(const bl_search_t* s, int sim, const int16_t* leaves, const vo
     int np2 = 1; while (np2 < A) np2 *= 2;
     const int W = np2 < 64 ? np2 : 64, iters = np2 / W;
     if (iters > 16) return BL_ETOOBIG;
-    hipLaunchKernelGGL(sim_finish_kernel, dim3(s->B), dim3(64), 0, (hipStream_t)stream, to_search(s), sim, leaves,
-                       (const uint16_t*)policy_raw, (const uint16_t*)value_raw, valid, leaf_seats, W, iters);
+    if (f32)
+        hipLaunchKernelGGL(sim_finish_kernel<float>, dim3(s->B), dim3(64), 0, (hipStream_t)stream, to_search(s), sim, leaves,
+                           (const float*)policy_raw, (const float*)value_raw, valid, leaf_seats, W, iters);
+    else
+        hipLaunchKernelGGL(sim_finish_kernel<uint16_t>, dim3(s->B), dim3(64), 0, (hipStream_t)stream, to_search(s), sim, leaves,
+                           (const uint16_t*)policy_raw, (const uint16_t*)value_raw, valid, leaf_seats, W, iters);
     return check_launch();
+}
+
+int bl_sim_finish(const bl_search_t* s, int sim, const int16_t* leaves, const void* policy_raw, const void* value_raw,
+                  const uint8_t* valid, const int32_t* leaf_seats, bl_stream_t stream) {
+    return sim_finish_impl(0, s, sim, leaves, policy_raw, value_raw, valid, leaf_seats, stream);
+}
+
+int bl_sim_finish_f32(const bl_search_t* s, int sim, const int16_t* leaves, const float* policy_raw, const float* value_raw,
+                      const uint8_t* valid, const int32_t* leaf_seats, bl_stream_t stream) {
+    return sim_finish_impl(1, s, sim, leaves, policy_raw, value_raw, valid, leaf_seats, stream);
 }
 
 int bl_rezero_relu_f16(const void* x, const void* y, const float* alpha, void* x_out, void* relu_out, long n,

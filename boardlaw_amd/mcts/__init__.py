@@ -340,6 +340,15 @@ class MCTS:
                                                       self._obs.data_ptr(), self._valid.data_ptr(),
                                                       self._leaf_seats.data_ptr(), self.counters.data_ptr(), st))
             world = LeafWorlds(self, self._leaves, self._obs, self._valid, self._leaf_seats)
+            if getattr(network, 'leaf_fp32', False) and hasattr(network, 'root_raw'):
+                # the exact mode (networks.Inference(precision='fp32')): the leaf is evaluated like the root -- fp32 Linears, fp32
+                # heads, only the stores rounded to f16 -- which is what the reference's CPU runs do (mcts/__init__.py:131-136)
+                policy_raw, value_raw = network.root_raw(world)
+                policy_raw, value_raw = policy_raw.float().contiguous(), value_raw.float().contiguous()
+                assert policy_raw.shape == (self.n_envs, self.n_actions) and value_raw.shape == (self.n_envs,)
+                _native.check(L.bl_sim_finish_f32(s, self.sim, self._leaves.data_ptr(), policy_raw.data_ptr(), value_raw.data_ptr(),
+                                                  self._valid.data_ptr(), self._leaf_seats.data_ptr(), st))
+                return
             fp = network.fused_params(self.n_envs) if (self.fuse_finish and hasattr(network, 'fused_params')) else None
             if (fp is not None and self._obs.dtype == torch.half and self.n_nodes <= 64 and self.n_actions <= 128
                     and fp['W'] >= 256 and fp['K0'] == 2 * self.n_actions and fp['NH'] == self.n_actions + 1):

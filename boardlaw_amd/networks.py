@@ -89,12 +89,23 @@ class Inference:
     # memory costs what a launch boundary costs.  Off.
     PERSIST_PLAN = False
 
-    def __init__(self, model, fused=False):
+    def __init__(self, model, fused=False, precision='fp16'):
         """fused=True additionally runs all Linears as ONE MFMA kernel (bl_mlp_forward_f16) when the width is a multiple
         of 128: same rounding points, but the GEMMs' summation order is the kernel's own, so outputs equal the autocast
-        module's to f16 rounding rather than bit for bit."""
+        module's to f16 rounding rather than bit for bit.
+        precision='fp32': the EXACT mode -- leaves are evaluated like the root, in fp32 with only the stores rounded to f16
+        (`decisions.logits.half()`, `decisions.v.half()`, boardlaw/mcts/__init__.py:131-136).  That is what the reference's
+        recorded CPU runs do (`torch.cuda.amp.autocast` is a no-op there), so a seeded search stores the reference's own f16
+        logits wherever the two f32 GEMM summation orders round to the same binary16 (tests/test_reference_fixtures.py:
+        test_fp32_leaves_replay_the_reference_search).  Linears: bl_root_mlp_f32 (fused=True) or the library's f32 GEMMs;
+        heads, store, backup and q-range: bl_sim_finish_f32.  Roughly 1.5x the fp16 plan's time per simulation; opt-in."""
+        if precision not in ('fp16', 'fp32'):
+            raise ValueError(f"precision must be 'fp16' or 'fp32', got {precision!r}")
         self.model = model
         self.fused = fused
+        self.precision = precision
+        self.leaf_fp32 = precision == 'fp32'
+        self.wants_half_obs = not self.leaf_fp32       # fp32 leaves read the reference's f32 observation layout
         self._static = None
         self._packed = None
         self._persist = {}          # bl_mlp_layers_persist_f16's error word per device

@@ -33,6 +33,47 @@ def init(backend=None):
     return rank, world
 
 
+def _cpulist(text):
+    """'0-3,8,10-11' -> {0,1,2,3,8,10,11} (the kernel's cpulist format)."""
+    cpus = set()
+    for part in text.strip().split(','):
+        if not part:
+            continue
+        lo, _, hi = part.partition('-')
+        cpus.update(range(int(lo), int(hi or lo) + 1))
+    return cpus
+
+
+def gpu_numa_node(local, sysfs='/sys'):
+    """NUMA node of GPU `local`, from its PCI address (sysfs: bus/pci/devices/<addr>/numa_node), or None when it cannot be told."""
+    try:
+        props = torch.cuda.get_device_properties(local)
+        addr = f'{props.pci_domain_id:04x}:{props.pci_bus_id:02x}:{props.pci_device_id:02x}.0'
+        node = int(open(os.path.join(sysfs, 'bus/pci/devices', addr, 'numa_node')).read())
+        return node if node >= 0 else None
+    except Exception:
+        return None
+
+
+def pin_to_numa_node(node, sysfs='/sys'):
+    """Restricts this process (and the threads it starts later) to the cores of NUMA node `node` that it may already run on.  One
+    process per GPU means one host thread per GPU issuing every launch and graph replay: on a two-socket box a rank scheduled on the
+    far socket pays the inter-socket hop on every doorbell and every event wait.  Returns a small report for the bench line:
+    {'numa_node', 'cpus' (how many it is pinned to), 'pinned'}; pins nothing when the node or its core list is unknown."""
+    before = os.sched_getaffinity(0)
+    report = {'numa_node': node, 'cpus': len(before), 'pinned': False}
+    if node is None:
+        return report
+    try:
+        cpus = _cpulist(open(os.path.join(sysfs, f'devices/system/node/node{node}/cpulist')).read()) & before
+        if cpus and cpus != before:
+            os.sched_setaffinity(0, cpus)
+            report.update(cpus=len(cpus), pinned=True)
+    except Exception:
+        pass
+    return report
+
+
 def shard(n_total, rank, world):
     """Contiguous, near-equal slice of an env axis of length n_total for `rank` (first ranks take the remainder)."""
     base, extra = divmod(n_total, world)

@@ -208,6 +208,15 @@ int bl_sim_backup(const bl_search_t* s, int sim, const int16_t* leaves /*(B)*/,
 int bl_sim_finish(const bl_search_t* s, int sim, const int16_t* leaves /*(B)*/, const void* policy_raw, const void* value_raw,
                   const uint8_t* valid /*(B,A)*/, const int32_t* leaf_seats /*(B)*/, bl_stream_t stream);
 
+/* bl_sim_finish for pre-head outputs in FP32: policy_raw (B,A) f32, value_raw (B) f32 -- the leaf evaluation of the reference's
+ * CPU configuration, where `torch.cuda.amp.autocast` (boardlaw/mcts/__init__.py:131-134) is a no-op, the network and its heads
+ * run in f32 and only the stores round (`decisions.logits.half()`, `decisions.v.half()`, :135-136).  Same heads, store, backup
+ * and q-range as bl_sim_finish; the masked log-softmax and tanh take f32 inputs.  With the Linears from bl_root_mlp_f32 this is
+ * the exact-mode leaf evaluation (networks.Inference(precision='fp32')): a seeded search then stores the reference's own f16
+ * logits wherever the two f32 GEMM summation orders round to the same binary16. */
+int bl_sim_finish_f32(const bl_search_t* s, int sim, const int16_t* leaves /*(B)*/, const float* policy_raw, const float* value_raw,
+                      const uint8_t* valid /*(B,A)*/, const int32_t* leaf_seats /*(B)*/, bl_stream_t stream);
+
 /* ReZero residual block tail under fp16 autocast (boardlaw/networks.py:17-18), fused: x_out = x + alpha*y (rounded
  * where torch rounds) and relu_out = relu(x_out); n f16 elements, alpha one f32 on the device. */
 int bl_rezero_relu_f16(const void* x, const void* y, const float* alpha, void* x_out, void* relu_out, long n,

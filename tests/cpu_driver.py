@@ -86,7 +86,7 @@ def collect(procs, timeout):
     return out
 
 
-def run_cpu_baseline(boardsize, nodes, width, depth, total_envs=4096, seconds_budget=24.0):
+def run_cpu_baseline(boardsize, nodes, width, depth, total_envs=4096, seconds_budget=24.0, single_envs=256):
     import oracle_lib
     oracle_lib.load(''); oracle_lib.load('_O0')            # build the checker libraries before the workers race for them
     P, nproc = physical_cores(), os.cpu_count()
@@ -99,8 +99,8 @@ def run_cpu_baseline(boardsize, nodes, width, depth, total_envs=4096, seconds_bu
         procs = launch(P, envs, t_par, weights, '', boardsize, nodes, time.time() + 3.0)
         par = collect(procs, timeout=t_par * 4 + 60)
         # (i) one process, and the -O0 build, side by side on two otherwise idle cores
-        procs = launch(1, 256, t_one, weights, '', boardsize, nodes, time.time() + 1.5) + \
-            launch(1, 256, t_one, weights, '_O0', boardsize, nodes, time.time() + 1.5)
+        procs = launch(1, single_envs, t_one, weights, '', boardsize, nodes, time.time() + 1.5) + \
+            launch(1, single_envs, t_one, weights, '_O0', boardsize, nodes, time.time() + 1.5)
         one = collect(procs, timeout=t_one * 6 + 60)
     if not par or len(one) < 2:
         return {'value': None, 'unit': 'sims/s', 'cores': P, 'nproc': nproc, 'kind': 'port', 'sample': 'workers failed'}
@@ -115,6 +115,6 @@ def run_cpu_baseline(boardsize, nodes, width, depth, total_envs=4096, seconds_bu
                   f'({sum(r["moves"] for r in par)} moves in total)',
         'single_thread': {'value': o2['sims'] / o2['seconds'], 'unit': 'sims/s', 'envs': o2['envs'], 'ns_per_descent_O2': ns(o2),
                           'ns_per_descent_O0': ns(o0), 'value_O0': o0['sims'] / o0['seconds'],
-                          'note': 'one process, 256 envs; -O0 = how the reference JIT-builds its sources (no -O flag, libm powf)'},
+                          'note': f'one process, {single_envs} envs; -O0 = how the reference JIT-builds its sources (no -O flag, libm powf)'},
         'ns_per_descent_parallel_O2': float(np.mean([ns(r) for r in par])),
     }

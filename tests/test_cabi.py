@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(L, s), f'{s} declared in the header but not exported'
         assert s in _native.SYMBOLS, f'{s} has no ctypes signature in boardlaw_amd/_native.py'
     assert sorted(_native.SYMBOLS) == syms
-    assert L.bl_abi_version() == 3
+    assert L.bl_abi_version() == 4
 
 
 def test_argument_validation_without_gpu():
