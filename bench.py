@@ -385,10 +385,18 @@ def dry_run(args):
     own = time.perf_counter() - t0
     elapsed = parallel.max_over_ranks(own, device='cpu')
     per_rank, seen = parallel.gather_over_ranks(float(rank + 1), device='cpu')
+    # the per-rank report of the real line (fold_fast, NUMA pinning) through the same collective; the dry run pins to node 0's cores
+    # when the box has that list (it changes nothing on a one-node container) and pretends rank 1 failed bl_selftest()
+    pinning = parallel.pin_to_numa_node(0 if os.path.exists('/sys/devices/system/node/node0/cpulist') else None)
+    fold = [int(x) for x in parallel.gather_over_ranks(float(rank != 1), device='cpu')[0]]
+    numa = [int(x) for x in parallel.gather_over_ranks(float(-1 if pinning['numa_node'] is None else pinning['numa_node']), device='cpu')[0]]
+    cpus = [int(x) for x in parallel.gather_over_ranks(float(pinning['cpus']), device='cpu')[0]]
     if rank == 0:
         print(json.dumps({'metric': 'mcts_sims_per_sec', 'value': 0.0, 'unit': 'sims/s', 'n_gpus': world, 'steps': args.steps,
                           'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed, 'dry_run': True, 'per_rank_values': per_rank,
-                          'ranks_seen': seen}))
+                          'ranks_seen': seen, 'baseline_config': 3 if (args.config == 2 and world > 1) else args.config,
+                          'ranks': {'per_rank_values': per_rank, 'ranks_seen': seen, 'min': min(per_rank), 'max': max(per_rank), 'mean': float(np.mean(per_rank)),
+                                    'fold_fast_per_rank': fold, 'numa_node_per_rank': numa, 'cpus_pinned_per_rank': cpus, 'pinned': pinning['pinned']}}))
     if world > 1:
         torch.distributed.destroy_process_group()
 

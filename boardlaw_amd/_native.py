@@ -59,6 +59,8 @@ SYMBOLS = {
     'bl_sim_n_leaves': (_i, [ctypes.POINTER(Search), _vp, _vp]),
     'bl_rezero_relu_f32': (_i, [_vp] * 5 + [ctypes.c_long, _vp]),
     'bl_sim_plant_root': (_i, [ctypes.POINTER(Search)] + [_vp] * 5 + [ctypes.c_float, _vp]),
+    'bl_sim_plant_root_gamma': (_i, [ctypes.POINTER(Search)] + [_vp] * 5 + [ctypes.c_float, _vp]),
+    'bl_categorical': (_i, [_vp, _vp, _vp, _i, _i, _vp]),
     'bl_sim_init': (_i, [ctypes.POINTER(Search), _vp, _vp, _vp]),
     'bl_sim_compact': (_i, [ctypes.POINTER(Search), _vp, _vp]),
     'bl_draw_actions': (_i, [_vp, _vp, _vp, _i, _i, _vp]),

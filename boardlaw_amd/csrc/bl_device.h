@@ -20,6 +20,17 @@ typedef _Float16 f16_t;
 __device__ __forceinline__ float h2f(uint16_t b) { return (float)__builtin_bit_cast(f16_t, b); }
 __device__ __forceinline__ uint16_t f2h(float f) { return __builtin_bit_cast(uint16_t, (f16_t)f); }
 
+// The q-range words IN MEMORY are the u32 codes below XOR BL_QBIAS, i.e. order-preserving as SIGNED int32 -- so that env shards on
+// several GPUs get the batch-global range of transition_q (cuda.cu:101-105) from ONE in-place int32 all-reduce(MAX) of the row
+// (parallel.allreduce_qrange: RCCL has no unsigned MAX through torch), with no widening launches around it.  The identity of the
+// signed MAX is the word 0x80000000 (= code 0): what the reset kernels write.  Inside the kernels the codes stay unsigned.
+#define BL_QBIAS 0x80000000u
+__device__ __forceinline__ void q_atomic_max(uint32_t* p, uint32_t code) { atomicMax((int*)p, (int)(code ^ BL_QBIAS)); }
+__device__ __forceinline__ void q_atomic_max_checked(uint32_t* p, uint32_t code) {       // a load first: skips the atomic when it cannot win
+    const int v = (int)(code ^ BL_QBIAS);
+    if (v > __hip_atomic_load((int*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax((int*)p, v);
+}
+
 // order-preserving float <-> u32
 __host__ __device__ __forceinline__ uint32_t enc(float f) {
     uint32_t b = __builtin_bit_cast(uint32_t, f);
@@ -143,7 +154,7 @@ __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
 // Reduce the 64 qrange slots: every lane of the wave returns {lo, hi}.  transition_q, cuda.cu:101-105.
 __device__ __forceinline__ void load_qrange(const uint32_t* qr, float& lo, float& hi) {
     const int lane = threadIdx.x & 63;
-    uint32_t a = qr[BL_QSTRIDE * lane], b = qr[BL_QSTRIDE * lane + 1];
+    uint32_t a = qr[BL_QSTRIDE * lane] ^ BL_QBIAS, b = qr[BL_QSTRIDE * lane + 1] ^ BL_QBIAS;
     a = wave_max_u32(a); b = wave_max_u32(b);       // DPP reductions + readlane (the shuffle butterflies were 12 LDS round trips)
     lo = dec(~a); hi = dec(b);
 }
@@ -151,6 +162,23 @@ __device__ __forceinline__ void load_qrange(const uint32_t* qr, float& lo, float
 __device__ __forceinline__ float readlane_f(float v, int lane) {
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
 }
+
+// ------------------------------------------------------------------------------------------------------------------
+// torch's reduce_kernel SUM over the last (contiguous) dimension of a (rows, A) f32 tensor, A < 128, as this torch build on ROCm
+// orders it (ATen/native/cuda/Reduce.cuh: setReduceConfig / thread_reduce_impl / block_x_reduce): block width
+// Wr = min(largest power of two <= A, 64); lane x < Wr adds v[x] and v[x + Wr] (when that exists) into two of its four
+// accumulators, combines them ((a0 + a1) + 0) + 0, and the lanes are then summed by shfl_down with offsets 1, 2, 4, ... Wr/2 --
+// the balanced tree ((v0+v1)+(v2+v3))+... that an XOR butterfly with the same offsets gives EVERY lane (float addition
+// commutes bit for bit).  `own` = this lane's v[x] (0 for x >= Wr), `second` = v[x + Wr] or 0.  Lets a kernel that holds a row
+// in registers reproduce `t.sum(-1)` bit for bit without the launch (A >= 128 takes torch's vectorised path, whose order depends
+// on each row's address alignment: callers keep torch's own kernels there).
+// ------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float torch_row_sum(float own, float second, int Wr) {
+    float v = (own + second) + 0.f + 0.f;
+    for (int off = 1; off < Wr; off <<= 1) v = v + __shfl_xor(v, off, BL_WAVE);
+    return v;
+}
+__host__ __device__ __forceinline__ int last_pow2_le(int a) { int w = 1; while (2 * w <= a) w *= 2; return w; }
 
 // ------------------------------------------------------------------------------------------------------------------
 // Hex.  Cell codes and rules: boardlaw/hex/cpp/cuda.cu:8-16,76-137; flood cuda.cu:18-74.

@@ -515,8 +515,8 @@ __device__ __forceinline__ void qrange_publish(uint32_t* qr, uint32_t nmin, uint
     nmin = gmaxu<64>(nmin); vmax = gmaxu<64>(vmax);
     if ((threadIdx.x & 63) == 0) {
         uint32_t* p = qr + BL_QSTRIDE * slot;
-        if (nmin > __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(p, nmin);
-        if (vmax > __hip_atomic_load(p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(p + 1, vmax);
+        q_atomic_max_checked(p, nmin);
+        q_atomic_max_checked(p + 1, vmax);
     }
 }
 
@@ -877,8 +877,8 @@ __global__ void __launch_bounds__(BL_WAVE) sim_finish_kernel(Search s, int sim, 
     nmin = wave_max_u32(nmin); vmax = wave_max_u32(vmax);
     if (lane == 0) {
         uint32_t* p = s.qrange + (long)BL_QWORDS * (sim + 1) + BL_QSTRIDE * (blockIdx.x % BL_QSLOTS);
-        if (nmin > __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(p, nmin);
-        if (vmax > __hip_atomic_load(p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(p + 1, vmax);
+        q_atomic_max_checked(p, nmin);
+        q_atomic_max_checked(p + 1, vmax);
     }
 }
 
@@ -950,9 +950,13 @@ __global__ void __launch_bounds__(256) rezero_relu_f32_kernel(const float* x, co
 //   v = scatter_values(tanh(value_raw), seats)
 //   decisions.logits[:, 0] = logits.half(); decisions.v[:, 0] = v.half()
 // ------------------------------------------------------------------------------------------------------------------
+// gamma_Wr > 0: `draw` holds torch's standard-gamma variates, not a finished Dirichlet sample -- the kernel first does what
+// at::_sample_dirichlet does after its gamma kernel (Distributions.cu: ret = gamma / gamma.sum(-1, keepdim); clamped to
+// [FLT_MIN, 1 - FLT_EPSILON]) with torch's summation order (torch_row_sum, A < 128), i.e. two launches fewer per move and
+// the same bits.
 __global__ void __launch_bounds__(BL_WAVE) sim_plant_root_kernel(Search s, const float* policy_raw, const float* value_raw,
                                                                 const uint8_t* valid, const int32_t* seats, const float* draw,
-                                                                float eps, int W, int iters) {
+                                                                float eps, int W, int iters, int gamma_Wr) {
     const int S = s.S, A = S * S, T = s.T;
     const int b = blockIdx.x, lane = threadIdx.x;
     const long envbase = (long)b * T;
@@ -970,12 +974,31 @@ __global__ void __launch_bounds__(BL_WAVE) sim_plant_root_kernel(Search s, const
                 if (a < A) {
                     const bool ok = valid[(long)b * A + a];
                     e[it] = ok ? policy_raw[(long)b * A + a] : -INFINITY;
-                    if (draw) d[it] = ok ? draw[(long)b * A + a] : 0.f;
+                    if (draw) d[it] = (ok || gamma_Wr) ? draw[(long)b * A + a] : 0.f;
                 }
                 mx = (it == 0) ? e[0] : ((mx > e[it]) ? mx : e[it]);
-                dsum += d[it];
             }
         }
+        if (gamma_Wr) {
+            // the Dirichlet sample from its gamma variates, over ALL actions (iters <= 2 here): lane x < Wr sums elements x and x + Wr
+            float own, second;
+            if (W == 64) { own = d[0]; second = d[1]; }                                  // A >= 64: Wr == W, the lane's own two elements
+            else if (gamma_Wr == W) { own = d[0]; second = 0.f; }                        // A a power of two: one element per lane
+            else { const float up = __shfl(d[0], (lane + gamma_Wr) & 63, BL_WAVE); own = lane < gamma_Wr ? d[0] : 0.f; second = (lane < gamma_Wr && lane + gamma_Wr < A) ? up : 0.f; }
+            const float gsum = torch_row_sum(own, second, gamma_Wr);
+#pragma unroll
+            for (int it = 0; it < 2; it++) {
+                const int a = lane + it * W;
+                if (it < iters && a < A) {
+                    float r = d[it] / gsum;
+                    r = (1.17549435e-38f > r) ? 1.17549435e-38f : r;
+                    r = ((1.f - 1.1920929e-07f) < r) ? (1.f - 1.1920929e-07f) : r;
+                    d[it] = valid[(long)b * A + a] ? r : 0.f;                             // dirichlet_noise: draw[~valid] = 0
+                } else d[it] = 0.f;
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < 16; it++) if (it < iters) dsum += d[it];
         for (int off = W / 2; off > 0; off /= 2) { const float o = __shfl_xor(mx, off, W); mx = (mx < o) ? o : mx; }
         float sum = 0.f;
 #pragma unroll
@@ -1035,7 +1058,10 @@ __global__ void __launch_bounds__(256) sim_init_kernel(Search s, const uint8_t* 
     grid_fill(s.n, B * T * 2, 0);
     grid_fill(s.rewards, B * T * 2 * 2, 0);
     grid_fill(s.terminal, B * T, 0);
-    grid_fill(s.qrange, (T + 1) * (size_t)BL_QWORDS * sizeof(uint32_t), 0);
+    {   // every q-range word = the identity of the signed MAX (bl_device.h: BL_QBIAS)
+        const size_t words = (T + 1) * (size_t)BL_QWORDS, step = (size_t)gridDim.x * blockDim.x;
+        for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < words; i += step) s.qrange[i] = BL_QBIAS;
+    }
     if (s.nk) grid_fill(s.nk, B * T * 2, 0);
     if (s.fav) grid_fill(s.fav, B * T * 2, 0xffff);
     if (s.path) { const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x; if (tid < B) s.path[tid * (T + 2)] = 0; }   // no previous descent
@@ -1079,8 +1105,8 @@ __global__ void __launch_bounds__(256) sim_init_worlds_kernel(Search s, const ui
 // descend #1 sees the untouched stats: every q is 0/1e-4 = 0, so its range is {0, 0}.  Separate launch: it must land
 // after the grid-wide zeroing of qrange above.
 __global__ void sim_init_qrange_kernel(Search s) {
-    s.qrange[BL_QWORDS * 1 + 0] = ~enc(0.f);
-    s.qrange[BL_QWORDS * 1 + 1] = enc(0.f);
+    s.qrange[BL_QWORDS * 1 + 0] = ~enc(0.f) ^ BL_QBIAS;
+    s.qrange[BL_QWORDS * 1 + 1] = enc(0.f) ^ BL_QBIAS;
 }
 
 // The three launches above as ONE, a workgroup per env (the lazy-reset move's form: 35 -> ~10 us of kernel time per move).  Env b's
@@ -1107,7 +1133,7 @@ __global__ void __launch_bounds__(256) sim_init_env_kernel(Search s, const uint8
     }
     const size_t words = (size_t)(T + 1) * BL_QWORDS, step = (size_t)gridDim.x * 256;
     for (size_t i = (size_t)b * 256 + tid; i < words; i += step)
-        s.qrange[i] = i == (size_t)BL_QWORDS ? ~enc(0.f) : (i == (size_t)BL_QWORDS + 1 ? enc(0.f) : 0u);
+        s.qrange[i] = (i == (size_t)BL_QWORDS ? ~enc(0.f) : (i == (size_t)BL_QWORDS + 1 ? enc(0.f) : 0u)) ^ BL_QBIAS;
 }
 
 // MCTS.n_leaves (mcts/__init__.py:151-152): nodes that exist (parents != -1) and have no child.  A node has a child
@@ -1175,8 +1201,68 @@ __global__ void __launch_bounds__(BL_WAVE) draw_actions_kernel(const uint16_t* p
     if (lane == 0) actions[b] = pick >= 0 ? pick : (lastpos >= 0 ? lastpos : 0);
 }
 
-__global__ void __launch_bounds__(256) zero_words_kernel(uint32_t* p, int n) {
-    for (int i = threadIdx.x; i < n; i += blockDim.x) p[i] = 0;
+// ------------------------------------------------------------------------------------------------------------------
+// MCTSAgent's action draw (mcts/__init__.py:221) as torch computes it, in ONE launch, one wave per env:
+//     torch.distributions.Categorical(logits=x).sample(),  x = root logits .float()
+//   = argmax(softmax(x - x.logsumexp(-1, keepdim=True)) / q),  q = empty_like(probs).exponential_(1)      [torch.multinomial, one draw]
+// operation for operation with the launches it replaces (amax; |m| == inf -> 0; sub; exp; sum -- torch_row_sum; log; add; sub;
+// the persistent softmax: lane l holds elements l, l + W, per-lane max and exp-sum in order, XOR butterflies with offsets W/2 .. 1;
+// two IEEE divisions; argmax with the lower index on ties).  q is drawn by torch's own exponential_ kernel, so the generator is
+// consumed exactly as by the reference's call.  A < 128.  tests/test_rng_stream.py: the actions equal torch's on the same q.
+// ------------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(BL_WAVE) categorical_kernel(const uint16_t* logits, const float* q, long long* actions, int A, int W, int iters, int Wr) {
+    __shared__ float tbuf[128];
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const uint16_t* lrow = logits + (long)b * A;
+    const float* qrow = q + (long)b * A;
+    float x[2], qq[2];
+#pragma unroll
+    for (int it = 0; it < 2; it++) {
+        const int a = lane + it * W;
+        const bool in = lane < W && it < iters && a < A;
+        x[it] = in ? h2f(lrow[a]) : -INFINITY;
+        qq[it] = in ? qrow[a] : 1.f;
+    }
+    // logsumexp (ReduceOps.cpp: logsumexp_out_impl)
+    float m = wave_max_f32((x[0] > x[1]) ? x[0] : x[1]);
+    if (fabsf(m) == INFINITY) m = 0.f;
+#pragma unroll
+    for (int it = 0; it < 2; it++) {
+        const int a = lane + it * W;
+        if (lane < W && it < iters && a < A) tbuf[a] = expf(x[it] - m);
+    }
+    __syncthreads();
+    const float own = lane < Wr ? tbuf[lane] : 0.f, second = (lane < Wr && lane + Wr < A) ? tbuf[lane + Wr] : 0.f;
+    const float lse = logf(torch_row_sum(own, second, Wr)) + m;
+    // softmax(x - lse) (PersistentSoftmax.cuh: softmax_warp_forward, is_log_softmax = false)
+    float y[2], e[2];
+    y[0] = x[0] - lse; y[1] = x[1] - lse;
+    float mx = y[0];
+    if (iters > 1) mx = (mx > y[1]) ? mx : y[1];
+    for (int off = W / 2; off > 0; off /= 2) { const float o = __shfl_xor(mx, off, BL_WAVE); mx = (mx < o) ? o : mx; }
+    float sum = 0.f;
+    e[0] = expf(y[0] - mx); sum += e[0];
+    if (iters > 1) { e[1] = expf(y[1] - mx); sum += e[1]; } else e[1] = 0.f;
+    for (int off = W / 2; off > 0; off /= 2) sum = sum + __shfl_xor(sum, off, BL_WAVE);
+    // argmax(probs / q), lower index on ties (ArgMaxOps)
+    float best = -INFINITY; int besta = 0x7fffffff;
+#pragma unroll
+    for (int it = 0; it < 2; it++) {
+        const int a = lane + it * W;
+        if (lane < W && it < iters && a < A) {
+            const float r = (e[it] / sum) / qq[it];
+            if (r > best || (r == best && a < besta) || r != r) { best = r; besta = a; }
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        const float ob = __shfl_xor(best, off, BL_WAVE); const int oa = __shfl_xor(besta, off, BL_WAVE);
+        if (ob > best || (ob == best && oa < besta)) { best = ob; besta = oa; }
+    }
+    if (lane == 0) actions[b] = besta == 0x7fffffff ? 0 : besta;
+}
+
+__global__ void __launch_bounds__(256) zero_words_kernel(uint32_t* p, int n, uint32_t word) {
+    for (int i = threadIdx.x; i < n; i += blockDim.x) p[i] = word;
 }
 
 }  // namespace bl
@@ -1267,7 +1353,11 @@ int bl_exp_table_host(float* t) {
 int bl_qrange_decode(const uint32_t* st, float* mm) {
     if (!st || !mm) return BL_EINVAL;
     uint32_t a = 0, b = 0;
-    for (int i = 0; i < BL_QSLOTS; i++) { if (st[BL_QSTRIDE * i] > a) a = st[BL_QSTRIDE * i]; if (st[BL_QSTRIDE * i + 1] > b) b = st[BL_QSTRIDE * i + 1]; }
+    for (int i = 0; i < BL_QSLOTS; i++) {
+        const uint32_t x = st[BL_QSTRIDE * i] ^ BL_QBIAS, y = st[BL_QSTRIDE * i + 1] ^ BL_QBIAS;       // memory words -> unsigned codes
+        if (x > a) a = x;
+        if (y > b) b = y;
+    }
     mm[0] = dec(~a); mm[1] = dec(b);
     return BL_OK;
 }
@@ -1275,7 +1365,7 @@ int bl_qrange_decode(const uint32_t* st, float* mm) {
 int bl_mcts_qrange(const void* w, const int16_t* n, int B, int T, int S, uint32_t* st, bl_stream_t stream) {
     if (!w || !n || !st || B <= 0 || T <= 0 || S <= 0) return BL_EINVAL;
     hipStream_t hs = (hipStream_t)stream;
-    hipLaunchKernelGGL(zero_words_kernel, dim3(1), dim3(256), 0, hs, st, BL_QWORDS);
+    hipLaunchKernelGGL(zero_words_kernel, dim3(1), dim3(256), 0, hs, st, BL_QWORDS, BL_QBIAS);
     const long nodes = (long)B * T;
     int blocks = (int)((nodes + 255) / 256); if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(qrange_kernel, dim3(blocks), dim3(256), 0, hs, (const uint16_t*)w, n, nodes, S, st);
@@ -1539,18 +1629,29 @@ int bl_rezero_relu_f32(const float* x, const float* y, const float* alpha, float
     return check_launch();
 }
 
-int bl_sim_plant_root(const bl_search_t* s, const float* policy_raw, const float* value_raw, const uint8_t* valid,
-                      const int32_t* seats, const float* draw, float eps, bl_stream_t stream) {
+static int plant_root_impl(const bl_search_t* s, const float* policy_raw, const float* value_raw, const uint8_t* valid,
+                           const int32_t* seats, const float* draw, float eps, int gamma, bl_stream_t stream) {
     int rc = search_check(s);
     if (rc) return rc;
-    if (!policy_raw || !value_raw || !valid || !seats) return BL_EINVAL;
+    if (!policy_raw || !value_raw || !valid || !seats || (gamma && !draw)) return BL_EINVAL;
     const int A = s->boardsize * s->boardsize;
     int np2 = 1; while (np2 < A) np2 *= 2;
     const int W = np2 < 64 ? np2 : 64, iters = np2 / W;
-    if (iters > 16) return BL_ETOOBIG;
+    if (iters > 16 || (gamma && A >= 128)) return BL_ETOOBIG;
+    const int Wr = gamma ? (last_pow2_le(A) < 64 ? last_pow2_le(A) : 64) : 0;
     hipLaunchKernelGGL(sim_plant_root_kernel, dim3(s->B), dim3(64), 0, (hipStream_t)stream, to_search(s), policy_raw, value_raw,
-                       valid, seats, draw, eps, W, iters);
+                       valid, seats, draw, eps, W, iters, Wr);
     return check_launch();
+}
+
+int bl_sim_plant_root(const bl_search_t* s, const float* policy_raw, const float* value_raw, const uint8_t* valid,
+                      const int32_t* seats, const float* draw, float eps, bl_stream_t stream) {
+    return plant_root_impl(s, policy_raw, value_raw, valid, seats, draw, eps, 0, stream);
+}
+
+int bl_sim_plant_root_gamma(const bl_search_t* s, const float* policy_raw, const float* value_raw, const uint8_t* valid,
+                            const int32_t* seats, const float* gamma, float eps, bl_stream_t stream) {
+    return plant_root_impl(s, policy_raw, value_raw, valid, seats, gamma, eps, 1, stream);
 }
 
 int bl_sim_root(const bl_search_t* s, int sim, void* probs, const void* log_table, void* logits, bl_stream_t stream) {
@@ -1573,6 +1674,16 @@ int bl_sim_root(const bl_search_t* s, int sim, void* probs, const void* log_tabl
 int bl_draw_actions(const void* probs, const float* uniforms, long long* actions, int B, int A, bl_stream_t stream) {
     if (!probs || !uniforms || !actions || B <= 0 || A <= 0) return BL_EINVAL;
     hipLaunchKernelGGL(draw_actions_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, (const uint16_t*)probs, uniforms, actions, A);
+    return check_launch();
+}
+
+int bl_categorical(const void* logits, const float* q, long long* actions, int B, int A, bl_stream_t stream) {
+    if (!logits || !q || !actions || B <= 0 || A <= 0) return BL_EINVAL;
+    if (A >= 128) return BL_ETOOBIG;           // torch's sum takes its vectorised path there (row-alignment-dependent order): the caller keeps torch's launches
+    int np2 = 1; while (np2 < A) np2 *= 2;
+    const int W = np2 < 64 ? np2 : 64, iters = np2 / W;
+    const int Wr = last_pow2_le(A) < 64 ? last_pow2_le(A) : 64;
+    hipLaunchKernelGGL(categorical_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, (const uint16_t*)logits, q, actions, A, W, iters, Wr);
     return check_launch();
 }
 

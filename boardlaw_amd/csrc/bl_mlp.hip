@@ -673,8 +673,9 @@ __global__ void __launch_bounds__(WAVES * 64) mlp_kernel(Params p, FinArgs f) {
             uint32_t* q = f.qrange + BLM_QSTRIDE * ((blockIdx.x * WAVES + wave) % BLM_QSLOTS);
             // unconditional: with one pair per wave (1024 per launch over 64 slots) the atomics are cheap, and a checking
             // load first would put a round trip at the very end of every workgroup
-            atomicMax(q, nmin);
-            atomicMax(q + 1, vmax);
+            // words in memory = the unsigned codes XOR 0x80000000, compared SIGNED (bl_device.h: BL_QBIAS; include/boardlaw_amd.h)
+            atomicMax((int*)q, (int)(nmin ^ 0x80000000u));
+            atomicMax((int*)(q + 1), (int)(vmax ^ 0x80000000u));
         }
     }
     CLK(40)

@@ -99,6 +99,29 @@ class MoveRng(TorchRng):
         # variates, their sum, the clamped quotient -- ATen's _sample_dirichlet), the same use of the generator
         return torch._sample_dirichlet(alpha.expand(*shape, alpha.shape[-1]), self.generator)
 
+    # torch's reduce kernel sums rows of fewer than 128 elements in a fixed lane layout that bl_sim_plant_root_gamma / bl_categorical
+    # reproduce; from 128 on it vectorises with an order that depends on each row's address alignment: torch's own launches stay
+    FUSED_MAX_ACTIONS = 127
+
+    def gamma_variates(self, alpha, shape):
+        """The standard-gamma variates torch's Dirichlet sampler starts from (at::_sample_dirichlet = _standard_gamma, then sum and
+        clamped quotient): the same kernel, the same use of the generator; bl_sim_plant_root_gamma does the rest inside the root's
+        launch with torch's rounding and summation order -- same bits as dirichlet(), two launches fewer per move."""
+        return torch._standard_gamma(alpha.expand(*shape, alpha.shape[-1]), self.generator)
+
+    def categorical_f16(self, logits):
+        """categorical(logits.float()) for (B,A) f16 device logits: torch's own exponential_ draw, then bl_categorical -- the
+        normalisation, softmax, quotient and argmax of the launches below as one kernel with torch's rounding points and summation
+        orders (tests/test_rng_stream.py::test_fused_draws_equal_torchs).  Same actions, same use of the generator."""
+        if not (logits.is_cuda and logits.dtype == torch.half and logits.ndim == 2 and logits.shape[-1] <= self.FUSED_MAX_ACTIONS):
+            return self.categorical(logits.float())
+        B, A = logits.shape
+        q = torch.empty((B, A), dtype=torch.float, device=logits.device).exponential_(1, generator=self.generator)
+        actions = torch.empty((B,), dtype=torch.long, device=logits.device)
+        with torch.cuda.device(logits.device):
+            _native.check(_native.lib().bl_categorical(logits.contiguous().data_ptr(), q.data_ptr(), actions.data_ptr(), B, A, _native.stream(logits.device)))
+        return actions
+
     def categorical(self, logits):
         """torch.distributions.Categorical(logits=logits).sample() with this rng's generator, minus argument checking: the
         normalisation and softmax of Categorical.__init__/probs, then what torch.multinomial does for ONE draw with replacement
@@ -263,14 +286,19 @@ class MCTS:
             policy_raw, value_raw = policy_raw.float().contiguous(), value_raw.float().contiguous()
             valid = world.valid.contiguous()
             alpha = _constant(self.n_actions, self.alpha_scale / self.n_actions, self.device, torch.float)
+            plant = _native.lib().bl_sim_plant_root
             if hasattr(self.rng, 'gamma'):
-                draw = self.rng.gamma(alpha, (self.n_envs,)).float().contiguous()
+                draw = self.rng.gamma(alpha, (self.n_envs,)).float().contiguous()      # FastRng: not the reference's normalisation
+            elif hasattr(self.rng, 'gamma_variates') and self.n_actions <= getattr(self.rng, 'FUSED_MAX_ACTIONS', 0):
+                # the reference's draw (mcts/__init__.py:16-18) with its normalisation inside the root's launch: same bits
+                draw = self.rng.gamma_variates(alpha, (self.n_envs,)).float().contiguous()
+                plant = _native.lib().bl_sim_plant_root_gamma
             else:
                 draw = self.rng.dirichlet(alpha, (self.n_envs,)).float().contiguous()  # mcts/__init__.py:16-18
             with torch.cuda.device(self.device):
-                _native.check(_native.lib().bl_sim_plant_root(ctypes.byref(self._search), policy_raw.data_ptr(), value_raw.data_ptr(),
-                                                              valid.data_ptr(), world.seats.int().contiguous().data_ptr(),
-                                                              draw.data_ptr(), float(self.noise_eps), _native.stream(self.device)))
+                _native.check(plant(ctypes.byref(self._search), policy_raw.data_ptr(), value_raw.data_ptr(),
+                                    valid.data_ptr(), world.seats.int().contiguous().data_ptr(),
+                                    draw.data_ptr(), float(self.noise_eps), _native.stream(self.device)))
             self.sim = 1
             return
         with torch.no_grad():
@@ -530,6 +558,8 @@ class MCTSAgent:
             actions = r.logits.argmax(-1)
         elif hasattr(m.rng, 'draw_actions') and m.fused:
             actions = m.rng.draw_actions(m._root_probs)
+        elif hasattr(m.rng, 'categorical_f16') and m.fused:
+            actions = m.rng.categorical_f16(r.logits)              # the same draw as below, in two launches instead of thirteen
         else:
             actions = m.rng.categorical(r.logits.float())
         d = arrdict.arrdict(

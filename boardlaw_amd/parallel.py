@@ -124,21 +124,19 @@ def gather_over_ranks(value, device=None):
 
 
 def merge_qrange(*states):
-    """Element-wise unsigned MAX of q-range states (int32 storage of u32 words): the state of the union of the shards.
-    This is the local form of allreduce_qrange."""
-    wide = torch.stack([s.to(torch.int64) & 0xffffffff for s in states]).amax(0)
-    return torch.where(wide >= 2**31, wide - 2**32, wide).to(torch.int32)
+    """Element-wise MAX of q-range states: the state of the union of the shards (the local form of allreduce_qrange).  The
+    words are order-preserving as SIGNED int32 (include/boardlaw_amd.h: the codes XOR 0x80000000), so this is a plain amax."""
+    return torch.stack(list(states)).amax(0)
 
 
 def allreduce_qrange(state):
-    """In-place all-reduce(MAX) of a q-range state (int32 storage of u32 words, any shape): afterwards every rank holds
-    the range over the union of all shards' envs.  The words are unsigned, the collective compares signed, so they
-    travel as int64."""
+    """In-place all-reduce(MAX) of a q-range state (int32, any shape): afterwards every rank holds the range over the union of
+    all shards' envs.  ONE collective on the row where it lies -- the kernels keep the words order-preserving as signed int32
+    precisely so that RCCL's int32 MAX is the right comparison (round 4 widened to int64 and back: six launches around it)."""
     if not dist.is_initialized():
         return state
-    wide = state.to(torch.int64) & 0xffffffff
-    dist.all_reduce(wide, op=dist.ReduceOp.MAX)
-    state.copy_(torch.where(wide >= 2**31, wide - 2**32, wide).to(torch.int32))
+    assert state.dtype == torch.int32
+    dist.all_reduce(state, op=dist.ReduceOp.MAX)
     return state
 
 

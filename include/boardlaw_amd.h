@@ -31,7 +31,7 @@ extern "C" {
 #define BL_ETOOBIG (-2)    /* A, T or S beyond what the kernels support (A <= 1024, T <= 32767, S <= 8, board <= 32) */
 #define BL_ELAUNCH (-3)    /* hipGetLastError() != hipSuccess after the launch (reference: C10_CUDA_CHECK) */
 
-#define BL_QRANGE_WORDS 4096 /* u32 words in one q-range state: 64 slots, one per 256 B, words 0/1 = {~enc(min), enc(max)} */
+#define BL_QRANGE_WORDS 4096 /* 32-bit words in one q-range state: 64 slots, one per 256 B, words 0/1 = {~enc(min), enc(max)} ^ 0x80000000 */
 
 typedef void* bl_stream_t; /* hipStream_t */
 
@@ -75,11 +75,14 @@ const char* bl_strerror(int code);
 int bl_exp_table_host(float* host_table /* 65536 floats, HOST memory */);
 
 /* ---- transition_q's batch-global range (boardlaw/mcts/cpp/cuda.cu:101-105) --------------------------------------
- * qrange_state: BL_QRANGE_WORDS x u32, device: 64 slots of {max of ~enc(q), max of enc(q)} over the slot's share of
- * the B*T*S values q = f32(w)/(f32(n)+1e-4f); enc = the order-preserving float->u32 map.  One slot per 256 B:
- * atomics on one cache line serialise in L2 (about 12 ns each, measured: 4096 waves x 2 atomics on 4 lines cost
- * ~25 us), on 64 lines they do not; consumers max-reduce the 64 slots with one wave-wide load.  bl_mcts_qrange zeroes the state itself (a kernel, not a memset node) and reduces into it; shards that want the reference's
- * *global* normalisation all-reduce(MAX) the words across ranks.  bl_qrange_decode turns a HOST copy into {min,max}. */
+ * qrange_state: BL_QRANGE_WORDS x 32-bit words, device: 64 slots of {max of ~enc(q), max of enc(q)} over the slot's share of
+ * the B*T*S values q = f32(w)/(f32(n)+1e-4f); enc = the order-preserving float->u32 map, and a word IN MEMORY is its code
+ * XOR 0x80000000, i.e. order-preserving as SIGNED int32 (the identity of the MAX is the word 0x80000000; ABI 4).  One slot
+ * per 256 B: atomics on one cache line serialise in L2 (about 12 ns each, measured: 4096 waves x 2 atomics on 4 lines cost
+ * ~25 us), on 64 lines they do not; consumers max-reduce the 64 slots with one wave-wide load.  bl_mcts_qrange resets the
+ * state itself (a kernel, not a memset node) and reduces into it.  Shards that want the reference's *global* normalisation
+ * all-reduce(MAX) the words across ranks AS int32, in place -- one collective, no conversion (that is what the signed
+ * representation is for: boardlaw_amd/parallel.py: allreduce_qrange).  bl_qrange_decode turns a HOST copy into {min,max}. */
 int bl_mcts_qrange(const void* w /*f16 (B,T,S)*/, const int16_t* n /*(B,T)*/, int B, int T, int S,
                    uint32_t* qrange_state, bl_stream_t stream);
 int bl_qrange_decode(const uint32_t host_state[BL_QRANGE_WORDS], float host_minmax[2]);
@@ -291,6 +294,22 @@ int bl_rezero_relu_f32(const float* x, const float* y, const float* alpha, float
  * scattered by seat, both rounded to f16 into node 0 of s->logits / s->v.  The caller then sets its sim counter to 1. */
 int bl_sim_plant_root(const bl_search_t* s, const float* policy_raw, const float* value_raw /*(B)*/, const uint8_t* valid,
                       const int32_t* seats /*(B)*/, const float* draw, float eps, bl_stream_t stream);
+
+/* bl_sim_plant_root fed torch's standard-gamma variates (B,A) f32 instead of a finished Dirichlet sample: the kernel first does
+ * what at::_sample_dirichlet does after its gamma kernel -- gamma / gamma.sum(-1), clamped to [FLT_MIN, 1 - FLT_EPSILON] -- with
+ * that sum in torch's own order (its reduce kernel's lane layout and tree on this build), so node 0's row carries the bits of
+ * the reference's `torch.distributions.Dirichlet(alpha).sample()` path (boardlaw/mcts/__init__.py:13-24) with two launches fewer
+ * per move.  A < 128 (beyond, torch's sum is address-alignment dependent): BL_ETOOBIG, the caller then draws the Dirichlet
+ * with torch and calls bl_sim_plant_root. */
+int bl_sim_plant_root_gamma(const bl_search_t* s, const float* policy_raw, const float* value_raw /*(B)*/, const uint8_t* valid,
+                            const int32_t* seats /*(B)*/, const float* gamma /*(B,A)*/, float eps, bl_stream_t stream);
+
+/* MCTSAgent's action draw exactly as torch makes it (boardlaw/mcts/__init__.py:221: Categorical(logits = root logits.float())
+ * .sample()), in one launch: actions[b] = argmax_a softmax(x - logsumexp(x))[a] / q[b,a] with x = f32(logits[b,:]) and q the
+ * Exponential(1) variates torch.multinomial draws (the caller makes them with torch's own exponential_ kernel, so the generator
+ * is consumed as by the reference's call) -- every intermediate rounded where torch's ~12 launches round it, sums in torch's
+ * order, the lower index on ties.  logits f16 (B,A), q f32 (B,A), actions i64 (B).  A < 128: BL_ETOOBIG otherwise. */
+int bl_categorical(const void* logits, const float* q, long long* actions_out, int B, int A, bl_stream_t stream);
 
 /* Builds the compacted rows (cpi, cca, nk) of node leaves[b] of every env -- node 0 when leaves is NULL -- from
  * logits[b,node,:]; for logits stored without one of the calls above (MCTS.plant_root's tensor assignment). */

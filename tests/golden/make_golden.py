@@ -612,6 +612,91 @@ def gen_learner(mcts_mod, hex_, networks, out):
     print('learner', {k: float(res[k]) for k in res if k.endswith('_loss')})
 
 
+# --------------------------------------------------------------------------------------------------------------
+# 11. Config 5's EVEN board sizes (round 5): whole searches at 4x4, 6x6, 8x8, 10x10 (the block counts of the fused descent's
+#     policy evaluation change at these sizes) and arena.evaluate at 2048 envs -- same recipes as gen_search / gen_arena, new files,
+#     so that the files of earlier rounds stay byte for byte what they were.
+# --------------------------------------------------------------------------------------------------------------
+def gen_search_even(mcts_mod, hex_, networks, mcuda, out):
+    # (name, S, B, T, width, depth, moves, seed, premix moves)
+    configs = [
+        ('search_4x4', 4, 48, 16, 16, 2, 4, 21, 3),
+        ('search_6x6', 6, 32, 48, 32, 2, 2, 22, 12),
+        ('search_8x8', 8, 32, 64, 32, 2, 2, 23, 21),
+        ('search_10x10', 10, 24, 64, 32, 2, 2, 24, 33),
+    ]
+    for name, S, B, T, width, depth, moves, seed, mix in configs:
+        res, _ = run_search_fixture(mcts_mod, hex_, networks, mcuda, S, B, T, width, depth, moves, seed, set(), mix)
+        np.savez_compressed(os.path.join(out, name + '.npz'), **res)
+        print(name, os.path.getsize(os.path.join(out, name + '.npz')) // 1024, 'KiB')
+
+
+def gen_arena_even(hex_, out):
+    common, neural = import_reference_arena()
+    res = {}
+    for S in (4, 6, 8, 10):
+        start = premixed_worlds(hex_, 2048, S, S * S // 3, 500 + S)
+        res[f'S{S}_board'] = np_(start.board); res[f'S{S}_seats'] = np_(start.seats)
+        results = common.evaluate(start.clone(), {'front': EdgeAgent(False, 1), 'back': EdgeAgent(True, 0)})
+        for i, r in enumerate(results):
+            res[f'S{S}_r{i}_names'] = np.array(r.names)
+            res[f'S{S}_r{i}_wins'] = np.array(r.wins); res[f'S{S}_r{i}_moves'] = np.array(r.moves); res[f'S{S}_r{i}_games'] = np.array(r.games)
+        print('arena', S, [(r.names, r.wins, r.moves) for r in results])
+    np.savez_compressed(os.path.join(out, 'arena_even.npz'), **res)
+
+
+# --------------------------------------------------------------------------------------------------------------
+# 12. validation.MonteCarloAgent and validation.SequentialMatrix (boardlaw/validation.py:32-77, 213-278; round 5).
+#     SequentialMatrix: dilemma() and antisymmetric() stepped with seeded actions, every field of every step on record.
+#     MonteCarloAgent: run on the reference's Hex (3x3, 4x4) and on SequentialMatrix with every Categorical draw it makes on
+#     record IN CALL ORDER (the rollouts' uniform draws over the valid actions, then the final draw from the logits), so that a
+#     replay needs no random stream of its own -- the GPU's generator is not the CPU's.
+# --------------------------------------------------------------------------------------------------------------
+def gen_validation(validation, hex_, out):
+    res = {}
+    for kind in ('dilemma', 'antisymmetric'):
+        torch.manual_seed(800)
+        world = getattr(validation.SequentialMatrix, kind)(n_envs=6, device='cpu')
+        rec = {k: [] for k in ('seats', 'moves', 'obs', 'valid', 'actions', 'rewards', 'terminal')}
+        res[f'{kind}_payoffs'] = np_(world.payoffs)
+        for t in range(7):
+            actions = torch.randint(2, (6,))
+            rec['seats'].append(np_(world.seats)); rec['moves'].append(np_(world.moves)); rec['obs'].append(np_(world.obs)); rec['valid'].append(np_(world.valid))
+            rec['actions'].append(np_(actions))
+            world, trans = world.step(actions)
+            rec['rewards'].append(np_(trans.rewards)); rec['terminal'].append(np_(trans.terminal))
+        rec['seats'].append(np_(world.seats)); rec['moves'].append(np_(world.moves))
+        for k, v in rec.items():
+            res[f'{kind}_{k}'] = np.stack(v)
+
+    draws = []
+    orig_sample = torch.distributions.Categorical.sample
+
+    def sample(self, shape=torch.Size()):
+        d = orig_sample(self, shape)
+        draws.append(d.clone())
+        return d
+    torch.distributions.Categorical.sample = sample
+    try:
+        cases = [('hex3_b1', lambda: premixed_worlds(hex_, 1, 3, 2, 810), 6, 1.), ('hex4_b1', lambda: premixed_worlds(hex_, 1, 4, 5, 811), 9, 2.),
+                 ('hex3_b5', lambda: premixed_worlds(hex_, 5, 3, 3, 812), 4, 1.),
+                 ('matrix_b1', lambda: validation.SequentialMatrix.dilemma(n_envs=1, device='cpu'), 7, 1.)]
+        for name, make, n_rollouts, temperature in cases:
+            world = make().clone()        # a fresh object: premixed_worlds assigns into its worlds in place, which leaves the reference's cached obs / valid stale
+            del draws[:]
+            torch.manual_seed(820)
+            d = validation.MonteCarloAgent(n_rollouts, temperature)(world)
+            if hasattr(world, 'board'):
+                res[f'mc_{name}_board'] = np_(world.board); res[f'mc_{name}_seats'] = np_(world.seats)
+            res[f'mc_{name}_meta'] = np.array([n_rollouts, temperature])
+            res[f'mc_{name}_logits'] = np_(d.logits); res[f'mc_{name}_actions'] = np_(d.actions); res[f'mc_{name}_v'] = np_(d.v)
+            res[f'mc_{name}_draw_sizes'] = np.array([len(x) for x in draws]); res[f'mc_{name}_draws'] = np.concatenate([np_(x) for x in draws])
+            print('montecarlo', name, len(draws), 'draws', d.logits.shape, np_(d.v))
+    finally:
+        torch.distributions.Categorical.sample = orig_sample
+    np.savez_compressed(os.path.join(out, 'validation.npz'), **res)
+
+
 if __name__ == '__main__':
     only = set(sys.argv[1:])          # e.g. `make_golden.py arena learner wide`: only those; no arguments: everything
     want = lambda name: not only or name in only
@@ -628,6 +713,8 @@ if __name__ == '__main__':
     if want('arena'): gen_arena(hex_, out)
     if want('rollout'): gen_rollout(hex_, out)
     if want('solitaire'): gen_solitaire(hex_, out)
+    if want('even'): gen_search_even(mcts_mod, hex_, networks, mcuda, out); gen_arena_even(hex_, out)
+    if want('validation'): gen_validation(validation, hex_, out)
 
 
 # tests/golden/learning.npz: produced by calling the reference's boardlaw.learning.reward_to_go / present_value on seeded

@@ -81,9 +81,19 @@ def test_qrange_decode_roundtrip():
     def enc(f):
         b = np.float32(f).view(np.uint32)
         return np.uint32(~b) if b & 0x80000000 else np.uint32(b | 0x80000000)
-    st = np.zeros(4096, np.uint32)
-    st[64 * 5] = ~enc(-3.5); st[64 * 5 + 1] = enc(0.25); st[64 * 9] = ~enc(1.0); st[64 * 9 + 1] = enc(-7.0)
+    # words in memory are the codes XOR 0x80000000: order-preserving as SIGNED int32, identity of the MAX = 0x80000000 (ABI 4)
+    bias = np.uint32(0x80000000)
+    st = np.full(4096, bias, np.uint32)
+    st[64 * 5] = ~enc(-3.5) ^ bias; st[64 * 5 + 1] = enc(0.25) ^ bias; st[64 * 9] = ~enc(1.0) ^ bias; st[64 * 9 + 1] = enc(-7.0) ^ bias
     assert _native.qrange_decode(torch.from_numpy(st.view(np.int32))).tolist() == [-3.5, 0.25]
+    # the signed order of the memory words is the order of the floats: a plain int32 max merges two states
+    vals = np.array([-7.0, -3.5, -0.0, 0.0, 1e-30, 0.25, 1.0, 65504.0], np.float32)
+    words = np.array([int(np.int32(enc(v) ^ bias)) for v in vals])
+    assert (np.diff(words) > 0).all()
+    from boardlaw_amd import parallel
+    other = np.full(4096, bias, np.uint32); other[64 * 7] = ~enc(-9.0) ^ bias; other[64 * 7 + 1] = enc(0.125) ^ bias
+    merged = parallel.merge_qrange(torch.from_numpy(st.view(np.int32)), torch.from_numpy(other.view(np.int32)))
+    assert _native.qrange_decode(merged).tolist() == [-9.0, 0.25]
 
 
 @pytest.mark.skipif(torch.cuda.is_available(), reason='checks the no-GPU behaviour')

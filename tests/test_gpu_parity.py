@@ -237,7 +237,8 @@ def premixed(oracle, B, S, moves, seed):
     return board, seats
 
 
-@pytest.mark.parametrize('S,B,T', [(9, 4096, 64), (5, 64, 16), (13, 1024, 48), (3, 16384, 8), (11, 333, 32), (13, 96, 256), (2, 5, 3), (9, 1, 64), (19, 24, 40), (32, 3, 12)])
+@pytest.mark.parametrize('S,B,T', [(9, 4096, 64), (5, 64, 16), (13, 1024, 48), (3, 16384, 8), (11, 333, 32), (13, 96, 256), (2, 5, 3), (9, 1, 64), (19, 24, 40), (32, 3, 12),
+                                   (4, 2048, 64), (6, 2048, 64), (7, 2048, 64), (8, 2048, 64), (10, 2048, 64)])     # config 5's sizes between 3 and 11 at its batch size
 def test_full_size_search_vs_oracle(oracle, S, B, T):
     """BASELINE config 2 at its full size (9x9, 4096 envs, 64 nodes) and neighbours: a whole search on the GPU against
     the oracle-driven search on the host, with a device-independent integer network.  Everything must be identical."""

@@ -33,8 +33,9 @@ def _worker(rank, world, port, out):
     rng = np.random.default_rng(7)
     q = rng.normal(size=(4099, 64, 2)).astype(np.float32) * 3
     mine = q[sl]
-    st = np.zeros(_native.QRANGE_WORDS, np.uint32)
-    st[64 * (rank * 3 % 64)] = ~_enc(mine.min()); st[64 * (rank * 3 % 64) + 1] = _enc(mine.max())
+    # words in memory = the unsigned codes XOR 0x80000000 (order-preserving as signed int32); untouched words = the MAX's identity
+    st = np.full(_native.QRANGE_WORDS, 0x80000000, np.uint32)
+    st[64 * (rank * 3 % 64)] = ~_enc(mine.min()) ^ np.uint32(0x80000000); st[64 * (rank * 3 % 64) + 1] = _enc(mine.max()) ^ np.uint32(0x80000000)
     state = torch.from_numpy(st.view(np.int32).copy())
     parallel.allreduce_qrange(state)
     lo, hi = _native.qrange_decode(state).tolist()
@@ -96,6 +97,48 @@ def test_bench_gpus_flag_spawns_one_rank_per_gpu():
     bad = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2'], env={**os.environ, 'WORLD_SIZE': '3', 'BENCH_DRY': '1'},
                          capture_output=True, text=True)
     assert bad.returncode != 0 and 'WORLD_SIZE=3' in bad.stderr
+
+
+def test_bench_eight_ranks_dry_run():
+    """The shape of the driver's 8-GPU run -- `bench.py --gpus 8` re-executing itself as eight ranks on 127.0.0.1, rendezvous,
+    barrier, max-over-ranks, every rank's figures through the collective, ONE JSON line -- on CPU ranks over gloo; under a launcher,
+    too (the driver's own command line: torch.distributed.run --nproc-per-node 8 ... bench.py --gpus 8)."""
+    import json, subprocess, sys
+    d = _bench(['--gpus', '8', '--steps', '1', '--warmup', '0'], {'BENCH_DRY': '1', 'BENCH_BACKEND': 'gloo'})
+    assert d['n_gpus'] == 8 and d['ranks_seen'] == 8 and d['per_rank_values'] == [float(r + 1) for r in range(8)]
+    assert d['ms_per_step'] >= 80.                                   # rank 7 sleeps 80 ms: the MAX over ranks
+    r = d['ranks']
+    assert r['min'] == 1.0 and r['max'] == 8.0 and r['mean'] == 4.5 and r['fold_fast_per_rank'] == [1, 0, 1, 1, 1, 1, 1, 1]
+    assert len(r['numa_node_per_rank']) == 8 and len(r['cpus_pinned_per_rank']) == 8 and all(c >= 1 for c in r['cpus_pinned_per_rank'])
+    assert d['baseline_config'] == 3
+    e = {**os.environ, 'BENCH_DRY': '1', 'BENCH_BACKEND': 'gloo'}
+    e.pop('WORLD_SIZE', None); e.pop('RANK', None)
+    out = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '8', '--master-addr', '127.0.0.1',
+                          '--master-port', str(_free_port()), os.path.join(ROOT, 'bench.py'), '--gpus', '8', '--steps', '2', '--warmup', '1'],
+                         env=e, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1 and json.loads(lines[0])['ranks_seen'] == 8
+
+
+def test_numa_pinning_helpers(tmp_path):
+    """parallel.pin_to_numa_node / gpu_numa_node against a fake sysfs: the cores of the GPU's node that this process may already
+    use, and nothing at all when the node is unknown."""
+    from boardlaw_amd import parallel
+    before = os.sched_getaffinity(0)
+    try:
+        keep = sorted(before)[:max(1, len(before) // 2)]
+        node = tmp_path / 'devices/system/node/node3'
+        node.mkdir(parents=True)
+        (node / 'cpulist').write_text(','.join(str(c) for c in keep) + ',100000-100003\n')      # cores outside the affinity mask are ignored
+        assert parallel._cpulist('0-3,8,10-11\n') == {0, 1, 2, 3, 8, 10, 11}
+        assert parallel.pin_to_numa_node(None, sysfs=str(tmp_path)) == {'numa_node': None, 'cpus': len(before), 'pinned': False}
+        assert parallel.pin_to_numa_node(5, sysfs=str(tmp_path))['pinned'] is False                 # no such node: left alone
+        rep = parallel.pin_to_numa_node(3, sysfs=str(tmp_path))
+        assert os.sched_getaffinity(0) == set(keep) and rep['cpus'] == len(keep) and rep['pinned'] == (set(keep) != before)
+        assert parallel.gpu_numa_node(0, sysfs=str(tmp_path)) is None                               # no GPU / no PCI entry: unknown
+    finally:
+        os.sched_setaffinity(0, before)
 
 
 @pytest.mark.gpu
@@ -188,6 +231,76 @@ dist.destroy_process_group()
     r = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and 'qrange sync ok' in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
     print([l for l in r.stdout.splitlines() if 'qrange sync ok' in l][-1])
+
+
+def _sharded_search_worker(rank, world, port, out):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK='0', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    import sys
+    for p in (ROOT, os.path.join(ROOT, 'tests')):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import oracle_lib
+    from gpu_util import HashNetwork, ReplayRng, bits16, to_np
+    from test_gpu_parity import oracle_search, premixed
+    from boardlaw_amd import parallel
+    from boardlaw_amd.hex import Hex
+    from boardlaw_amd.mcts import MCTS
+    torch.cuda.set_device(0)
+    torch.distributed.init_process_group('gloo', rank=rank, world_size=world)
+    orc = oracle_lib.load()
+    S, B, T = 9, 384, 40
+    board, seats = premixed(orc, B, S, 27, seed=91)
+    rands = np.random.default_rng(17).random((T - 1, B, T)).astype(np.float16).view(np.uint16)
+    want = oracle_search(orc, board, seats, T, rands)                  # ONE search over all B envs: the batch-global q range
+    sl = parallel.shard(B, rank, world)
+    calls = [0]
+
+    def sync(row):
+        # the real exchange between the two processes: the row travels through the gloo collective (staged through the host: the
+        # ranks share one GPU here, and RCCL refuses two ranks on one device) as the int32 words it is made of -- ONE all-reduce(MAX)
+        calls[0] += 1
+        host = row.cpu()
+        parallel.allreduce_qrange(host)
+        row.copy_(host)
+    world_ = Hex(board=torch.from_numpy(board[sl]).cuda(), seats=torch.from_numpy(seats[sl]).cuda())
+    net = HashNetwork('cuda')
+    m = MCTS(world_, n_nodes=T, rng=ReplayRng(np.ascontiguousarray(rands[:, sl]), 'cuda'), noise_eps=0., qrange_sync=sync)
+    d = net(world_)
+    m.plant_root(d.logits, d.v)
+    for _ in range(T - 1):
+        m.simulate(net)
+    same = all(np.array_equal(to_np(mine), theirs[sl]) for mine, theirs in
+               [(m.tree.children, want.children), (m.tree.parents, want.parents), (m.stats.n, want.n), (m.stats.w, want.w),
+                (m.worlds.board, want.boards), (m.decisions.logits, want.logits)])
+    same = same and np.array_equal(bits16(m.root_probs()), want.root_probs()[sl])
+    # ... and WITHOUT the exchange the shard normalises over its own envs and parts from the unsharded search somewhere
+    m2 = MCTS(world_, n_nodes=T, rng=ReplayRng(np.ascontiguousarray(rands[:, sl]), 'cuda'), noise_eps=0.)
+    m2.plant_root(d.logits, d.v)
+    for _ in range(T - 1):
+        m2.simulate(net)
+    differs = not np.array_equal(to_np(m2.stats.n), want.n[sl])
+    out.put((rank, bool(same), calls[0], bool(differs)))
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_sharded_search_with_the_qrange_collective_equals_the_unsharded_search():
+    """SURVEY 8e option 2 through a REAL collective between two processes: two ranks, each searching its shard
+    of 384 envs with MCTS(qrange_sync=...) -- one int32 all-reduce(MAX) of the q-range row per simulation -- reproduce, each on its
+    own envs, the ONE unsharded search of all 384 envs (the oracle's) bit for bit; without the exchange they do not."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context('spawn')
+    out = ctx.Queue()
+    procs = [ctx.Process(target=_sharded_search_worker, args=(r, world, port, out)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(out.get(timeout=600) for _ in range(world))
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert [r[1] for r in res] == [True, True], res
+    assert all(r[2] == 39 for r in res), res
+    assert any(r[3] for r in res), 'the shards agree with the unsharded search even without the exchange: the test shows nothing'
 
 
 @pytest.mark.gpu

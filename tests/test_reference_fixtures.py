@@ -94,9 +94,13 @@ def _check_chunk_evaluator(g, S, kind, device):
     assert np.array_equal(ev.wins.cpu().numpy(), g[f'chunk{S}_final_wins']) and np.array_equal(ev.moves.cpu().numpy(), g[f'chunk{S}_final_moves'])
 
 
-@pytest.mark.parametrize('S', [3, 5, 7])
+def _arena_gold(S):
+    return _gold('arena_even.npz' if S % 2 == 0 else 'arena.npz')      # even sizes: round 5 (make_golden.py: gen_arena_even)
+
+
+@pytest.mark.parametrize('S', [3, 4, 5, 6, 7])
 def test_arena_evaluate_matches_reference_cpu(oracle, S):
-    _check_evaluate(_gold('arena.npz'), S, oracle_hex(oracle), 'cpu')
+    _check_evaluate(_arena_gold(S), S, oracle_hex(oracle), 'cpu')
 
 
 @pytest.mark.parametrize('S', [5, 9])
@@ -105,11 +109,12 @@ def test_chunk_evaluator_matches_reference_cpu(oracle, S):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('S', [3, 5, 7, 9, 11])
+@pytest.mark.parametrize('S', [3, 4, 5, 6, 7, 8, 9, 10, 11])
 def test_arena_evaluate_matches_reference_gpu(S):
-    """config 5's shape -- 2048 envs per board size through arena.evaluate's masked variable-size calls -- on the product's Hex."""
+    """config 5's shape -- 2048 envs per board size, every size of the sweep 3..11, through arena.evaluate's masked variable-size
+    calls -- on the product's Hex."""
     from boardlaw_amd.hex import Hex
-    _check_evaluate(_gold('arena.npz'), S, Hex, 'cuda')
+    _check_evaluate(_arena_gold(S), S, Hex, 'cuda')
 
 
 @pytest.mark.gpu
@@ -173,6 +178,92 @@ def test_one_player_hex_matches_reference_cpu(oracle, kind_name, S):
 def test_one_player_hex_matches_reference_gpu(kind_name, S):
     from boardlaw_amd.hex import Hex
     _check_solitaire(_gold('solitaire.npz'), kind_name, S, Hex, 'cuda')
+
+
+# ------------------------------------------------------------------- validation.MonteCarloAgent / SequentialMatrix (round 5)
+def _check_sequential_matrix(g, device):
+    """validation.npz: the reference's SequentialMatrix.dilemma() / antisymmetric() (validation.py:213-278) stepped with recorded
+    actions: payoffs, seats, moves, obs, valid before every step, rewards and terminal after it, identical."""
+    from boardlaw_amd import validation
+    for kind in ('dilemma', 'antisymmetric'):
+        w = getattr(validation.SequentialMatrix, kind)(n_envs=6, device=device)
+        assert w.n_seats == 2 and w.n_envs == 6 and np.array_equal(w.payoffs.cpu().numpy(), g[f'{kind}_payoffs'])
+        for t in range(g[f'{kind}_actions'].shape[0]):
+            assert np.array_equal(w.seats.cpu().numpy(), g[f'{kind}_seats'][t]) and np.array_equal(w.moves.cpu().numpy(), g[f'{kind}_moves'][t]), (kind, t)
+            assert np.array_equal(w.obs.cpu().numpy(), g[f'{kind}_obs'][t]) and np.array_equal(w.valid.cpu().numpy().astype(np.uint8), g[f'{kind}_valid'][t])
+            w, trans = w.step(torch.from_numpy(g[f'{kind}_actions'][t]).to(device))
+            assert np.array_equal(trans.rewards.cpu().numpy(), g[f'{kind}_rewards'][t]), (kind, t)
+            assert np.array_equal(trans.terminal.cpu().numpy().astype(np.uint8), g[f'{kind}_terminal'][t]), (kind, t)
+        assert np.array_equal(w.seats.cpu().numpy(), g[f'{kind}_seats'][-1]) and np.array_equal(w.moves.cpu().numpy(), g[f'{kind}_moves'][-1])
+
+
+class _ReplayedDraws:
+    """Serves the Categorical draws the reference made, in call order (validation.npz: mc_*_draws)."""
+
+    def __init__(self, g, name, device):
+        sizes = g[f'mc_{name}_draw_sizes']
+        offsets = np.concatenate([[0], np.cumsum(sizes)])
+        self.draws = [torch.from_numpy(g[f'mc_{name}_draws'][a:b]).to(device) for a, b in zip(offsets[:-1], offsets[1:])]
+        self.i = 0
+
+    def __call__(self, probs=None, logits=None):
+        d = self.draws[self.i]; self.i += 1
+        given = probs if probs is not None else logits
+        assert d.shape == given.shape[:-1], 'the reference drew for a different batch here'
+        if probs is not None:
+            assert bool((probs.gather(-1, d[:, None]) > 0).all()), 'the recorded draw is not a legal move in this position'
+        return d
+
+
+def _check_monte_carlo(g, name, kind, device, exact):
+    """validation.MonteCarloAgent (validation.py:32-77) with the reference's draws replayed: the playouts must visit the positions
+    the reference's visited (every recorded draw is legal where it is replayed, every batch has the recorded size, none is left
+    over) and logits / actions / v must be the reference's -- bit for bit on the CPU; on the GPU v and the -inf pattern exactly and
+    the finite logits within 2 f32 ulp (torch's log_softmax kernel there is not the CPU's)."""
+    from boardlaw_amd import validation
+    n_rollouts, temperature = g[f'mc_{name}_meta']
+    if kind is None:
+        world = validation.SequentialMatrix.dilemma(n_envs=1, device=device)
+    else:
+        world = kind(board=torch.from_numpy(g[f'mc_{name}_board']).to(device), seats=torch.from_numpy(g[f'mc_{name}_seats']).to(device))
+    sampler = _ReplayedDraws(g, name, device)
+    d = validation.MonteCarloAgent(int(n_rollouts), float(temperature), sampler=sampler)(world)
+    assert sampler.i == len(sampler.draws), 'the reference made more draws: its playouts were longer'
+    assert np.array_equal(d.actions.cpu().numpy(), g[f'mc_{name}_actions'])
+    assert np.array_equal(d.v.cpu().numpy().view(np.uint32), g[f'mc_{name}_v'].view(np.uint32))
+    got, want = d.logits.cpu().numpy(), g[f'mc_{name}_logits']
+    if exact:
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    else:
+        fin = np.isfinite(want)
+        assert np.array_equal(np.isfinite(got), fin) and np.array_equal(got[~fin], want[~fin])
+        assert np.abs(got[fin].view(np.int32).astype(np.int64) - want[fin].view(np.int32)).max() <= 2
+
+
+MC_CASES = ['hex3_b1', 'hex4_b1', 'hex3_b5', 'matrix_b1']
+
+
+def test_sequential_matrix_matches_reference_cpu():
+    _check_sequential_matrix(_gold('validation.npz'), 'cpu')
+
+
+@pytest.mark.parametrize('name', MC_CASES)
+def test_monte_carlo_agent_matches_reference_cpu(oracle, name):
+    _check_monte_carlo(_gold('validation.npz'), name, None if name.startswith('matrix') else oracle_hex(oracle), 'cpu', exact=True)
+
+
+@pytest.mark.gpu
+def test_sequential_matrix_matches_reference_gpu():
+    _check_sequential_matrix(_gold('validation.npz'), 'cuda')
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('name', ['hex3_b1', 'hex4_b1', 'matrix_b1'])
+def test_monte_carlo_agent_matches_reference_gpu(name):
+    """One env per case on the GPU: with several, the reference's (B,B)-broadcast tally writes collide without accumulation and
+    which write wins is not defined on a GPU (boardlaw_amd/validation.py: MonteCarloAgent); that case is pinned on the CPU."""
+    from boardlaw_amd.hex import Hex
+    _check_monte_carlo(_gold('validation.npz'), name, None if name.startswith('matrix') else Hex, 'cuda', exact=False)
 
 
 # -------------------------------------------------------------------------------------------------------------- learner
