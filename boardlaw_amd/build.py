@@ -6,6 +6,7 @@
 hipcc cross-compiles without a GPU, so this runs in the build container; the .so files then travel with the tree.  Every
 translation unit is compiled to its own object (in parallel, only when stale) and the objects are linked: touching one
 kernel file costs one file's compile time."""
+import glob
 import os
 import shutil
 import subprocess
@@ -15,7 +16,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 UNITS = ('bl_kernels.hip', 'bl_expand.hip', 'bl_mlp.hip', 'bl_root.hip', 'bl_rand.hip')
 SOURCES = [os.path.join(HERE, 'csrc', f) for f in UNITS]
-HEADERS = [os.path.join(ROOT, 'include', 'boardlaw_amd.h')] + [os.path.join(HERE, 'csrc', h) for h in ('bl_device.h', 'bl_host.h')]
+# every header under csrc/ (bl_device.h includes bl_powf.h, ...): editing any of them rebuilds every object
+HEADERS = [os.path.join(ROOT, 'include', 'boardlaw_amd.h')] + sorted(glob.glob(os.path.join(HERE, 'csrc', '*.h')))
 OBJDIR = os.path.join(HERE, 'build')
 LIB = os.path.join(HERE, 'libboardlaw_amd.so')
 GEN_SRC = os.path.join(HERE, 'csrc', 'bl_torchgen.cpp')
