@@ -43,6 +43,18 @@ BOARD, ENVS, NODES, WIDTH, DEPTH = 9, 4096, 64, 512, 4
 HBM_PEAK_GBS = 8000.0
 
 
+def emit(line):
+    """The run's ONE JSON line, as the LAST thing on stdout: RCCL prints its version banner through C stdio, which (not a tty) holds
+    it back until exit -- after Python's line -- unless it is flushed first."""
+    import ctypes
+    try:
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    sys.stdout.flush()
+    print(json.dumps(line), flush=True)
+
+
 def premix(worlds, moves, gen):
     """floor(S^2/3) uniformly random legal moves per env; the reference's learning.mix plays 2500."""
     for _ in range(moves):
@@ -348,7 +360,7 @@ def arena_config(args):
         out['cpu_baseline'] = cpu_baseline(envs=B)
         if isinstance(out['cpu_baseline'].get('sample'), str):
             out['cpu_baseline']['sample'] = 'config 5 sample: the 9x9 share of the sweep as plain self-play -- ' + out['cpu_baseline']['sample']
-    print(json.dumps(out))
+    emit(out)
     if world > 1:
         torch.distributed.destroy_process_group()
 
@@ -524,9 +536,9 @@ def main():
 
     if args.timed_only:
         if rank == 0:
-            print(json.dumps({'metric': 'mcts_sims_per_sec', 'value': value, 'unit': 'sims/s', 'n_gpus': world, 'steps': args.steps,
-                              'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps, 'timed_only': True,
-                              'per_rank_values': per_rank_values, 'ranks_seen': ranks_seen, 'ranks': rank_report}))
+            emit({'metric': 'mcts_sims_per_sec', 'value': value, 'unit': 'sims/s', 'n_gpus': world, 'steps': args.steps,
+                  'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps, 'timed_only': True,
+                  'per_rank_values': per_rank_values, 'ranks_seen': ranks_seen, 'ranks': rank_report})
         if world > 1:
             torch.distributed.destroy_process_group()
         return
@@ -748,7 +760,7 @@ def main():
             # a bounded sample of THIS configuration's search on the host cores (config 4: 64 envs per process -- one 13x13 / 256-sim /
             # 1024x8 move of 64 envs is ~0.3 TFLOP of f32 numpy per process)
             out['cpu_baseline'] = cpu_baseline(envs=args.envs, single_envs=256 if default_shape else min(64, args.envs))
-        print(json.dumps(out))
+        emit(out)
     if world > 1:
         torch.distributed.destroy_process_group()
 
