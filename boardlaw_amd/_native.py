@@ -125,8 +125,7 @@ def tune(device=None):
     parity tests of the kernel variants); the library itself reads no environment."""
     return Tune(fold_fast=fold_fast(device) if device is not None else 0, expand_waves=_env_int('BL_EXPAND_WAVES'),
                 expand_deep=_env_int('BL_EXPAND_DEEP'), expand_legacy=_env_int('BL_EXPAND_LEGACY'), group=_env_int('BL_FORCE_GROUP'),
-                mlp_no_xcd=int(os.environ.get('BL_MLP_XCD', '1') == '0'), expand_envs=_env_int('BL_EXPAND_ENVS'),
-                expand_help=_env_int('BL_EXPAND_HELP'), powf_libm=_env_int('BL_POWF_LIBM'))
+                mlp_no_xcd=int(os.environ.get('BL_MLP_XCD', '1') == '0'), powf_libm=_env_int('BL_POWF_LIBM'))
 
 
 GENLIBPATH = os.path.join(HERE, 'libbl_torchgen.so')

@@ -464,399 +464,10 @@ __global__ void __launch_bounds__(BL_WAVE * NW, (RMAX <= 3 ? 8 : 4)) sim_expand2
     }
 }
 
-// ------------------------------------------------------------------------------------------------------------------
-// Round 4: NE envs per workgroup, and the waves of an env that has finished its descent help the envs still going.
-//
-// tools/deep_only_probe.py (profiles/r04_deep_only.txt) launches the kernel above on subsets of a search's envs: at simulation 63
-// of the bench workload the ONE deepest env (24 levels) alone takes 50 us of the whole launch's 67 us (eager), the 1024 deepest
-// alone 50 us, everything BUT the 1024 deepest 41 us -- a launch is its deepest descent's chain of batches (about 1.4 us per
-// level: a batch of two guessed levels is a memory trip for the rows, ~4.5 Newton iterations of ~730 cycles, the draw and the
-// hand-over) plus ~17 us of everybody else being in the way.  What shortens that chain is more guessed levels per batch; what
-// forbids it for every env is the chip's 8192 wave slots (four waves per env: 82 us).  So a workgroup here owns NE envs with two
-// waves each -- the same 8192 waves -- and a wave whose own env has finished (most descents are 2..6 levels) joins the env of
-// its workgroup that is still going: batches of 4, 6, 8 guessed levels for exactly the descents that are long, with waves
-// that would otherwise have left the chip.  Every level's result is still the exact evaluation of the node the descent is at
-// (evaluate_node is the batch evaluation of sim_expand2_kernel, instruction for instruction); which wave computes it changes
-// nothing.
-//
-// No workgroup barrier couples the envs (a first version that ran all waves of a workgroup through the batches in step, two
-// barriers per batch, was bit-exact and 20-50 % SLOWER: under eight waves per SIMD the SIMDs arbitrate oldest-first, waves
-// advance at very different rates, and a barrier hands every env the pace of the workgroup's slowest wave --
-// profiles/r04_shared_wg_lockstep_ab.txt).  An env's even wave is its LEADER: it owns the descent's state, lays out a batch
-// (task[e][k] = node, info, uniform for position k), publishes it with one LDS word (ev[e][EV_GO] = batch number, positions),
-// evaluates position 0 itself and walks through the results, waiting for position k's (res[e][k], tagged with the batch
-// number) only when the walk gets there.  Every other wave is a MEMBER: it polls its env's EV_GO word (s_sleep between
-// polls), evaluates the node of its position and posts the result; when its env has ended (EV_FIN) it takes a ticket of another
-// env of the workgroup that still goes (at or beyond level `help_thresh`, below `maxw` waves; the fewest waves first, the deepest
-// among equals) and serves that one -- the leader counts tickets when it lays out the next batch.  A leader expands its env
-// as soon as the descent has ended (the board goes through LDS with wave-scope fences) and then becomes a member itself.
-// Ordering: a wave's LDS operations execute in order; payload and flag are separated by workgroup-scope release/acquire fences.
-// ------------------------------------------------------------------------------------------------------------------
-template <int RMAX, bool FAST>
-__device__ __forceinline__ void evaluate_node(const Search& s, const long envbase, const int A, const int t, const int tinfo, const float rnd,
-                                              const float cpuct, const uint32_t qp, const int nn, int& action_o, int& child_o, int& sel_o) {
-    const int lane = threadIdx.x & 63;
-    const bool lowhalf = lane < 32;
-    const int el = lane & 31;
-    const int nk = tinfo & 0xffff, seat = (tinfo >> 16) & 1;
-    const int R = (nk + 31) >> 5;
-    const long row = (envbase + t) * A;
-    float top[RMAX], q[RMAX], term[RMAX], x[RMAX];
-    uint32_t cc[RMAX];
-    bool in[RMAX];
-#pragma unroll
-    for (int r = 0; r < RMAX; r++) {
-        const int e = 32 * r + el;
-        in[r] = (r < R) && (e < nk);
-        top[r] = 0.f; cc[r] = 0xffff0000u; q[r] = 0.f; term[r] = 0.f; x[r] = 0.f;
-        if (in[r]) { top[r] = s.cpi[row + e]; cc[r] = s.cca[row + e]; }
-    }
-    int Nloc = 0;
-#pragma unroll
-    for (int r = 0; r < RMAX; r++) {
-        if (r < R) {                                                  // wave-uniform: the bpermutes run with every lane enabled
-            const int c = (int)(int16_t)(cc[r] >> 16);
-            const bool ex = c >= 0;
-            const int src = ex ? c : 0;
-            const uint32_t q2 = (uint32_t)bperm_i(src & 63, (int)qp);
-            const int nv = bperm_i(src & 63, nn);
-            if (ex) q[r] = h2f((uint16_t)(seat ? (q2 >> 16) : q2));
-            if (lowhalf && in[r]) Nloc += ex ? nv : 1;
-        }
-    }
-    const int N = wave_sum_i32(Nloc) + (A - nk);                      // dropped actions are unexpanded: +1 each
-    const float lam = (cpuct * (float)N) / (float)(unsigned)(N + A);
-    float alpha = (nk < A) ? 1.e-4f : 0.f;                            // a dropped action's q + max(lambda pi, 1e-4)
-#pragma unroll
-    for (int r = 0; r < RMAX; r++) {
-        top[r] = lam * top[r];
-        if (in[r]) alpha = fmaxf(alpha, q[r] + fmaxf(top[r], 1.e-4f));
-    }
-    alpha = wave_max_f32(alpha);
-
-    // newton_search, cuda.cu:35-68; body per block count, quotients side by side (see sim_expand2_kernel)
-    float err = INFINITY;
-    const int last_e = nk - 1, rl = last_e >> 5;
-    const int laneS = (last_e & 31) + ((rl & 1) ? 32 : 0), laneG = (last_e & 31) + ((rl & 1) ? 0 : 32);
-    auto newton = [&](auto rr_c) __attribute__((always_inline)) {
-        constexpr int RR = decltype(rr_c)::value;
-        for (int it = 0; it < 101 && nk > 0; it++) {
-            float num[RR], den[RR], quo[RR];
-#pragma unroll
-            for (int r = 0; r < RR; r++) {
-                const bool isS = lowhalf != ((r & 1) != 0);
-                const float bot = alpha - q[r];
-                num[r] = isS ? top[r] : -top[r];
-                den[r] = isS ? bot : bot * bot;
-            }
-            ieee_div_n<RR>(num, den, quo);
-#pragma unroll
-            for (int r = 0; r < RR; r++) term[r] = quo[r];
-#pragma unroll
-            for (int r = 0; r < RR; r++) {
-                x[r] = term[r];
-                if (r == 0) { if (el == 0) x[0] = 0.f + x[0]; }          // the sums start from 0.f (cuda.cu:44): (+0) + (-0) = +0
-                else fold_carry<FAST>(x[r], x[r - 1 < 0 ? 0 : r - 1], term[r]);
-                fold_block<FAST>(x[r], term[r], r + 1 < RR ? 32 : nk - 32 * r);
-            }
-            const float Ssum = readlane_f(x[RR - 1], laneS), gsum_ = readlane_f(x[RR - 1], laneG);      // rl == RR - 1
-            if (it == 100) break;      // alpha moved after the 100th fold (cuda.cu:48-65): this pass only refreshed the terms
-            const float ne = Ssum - 1.f;
-            if ((ne < 1e-3f) || (err == ne)) break;
-            alpha -= ne / gsum_; err = ne;
-        }
-    };
-    static_assert(RMAX <= 6, "evaluate_node: up to 192 actions");
-    if (R <= 1) newton(std::integral_constant<int, 1>{});
-    else if (R == 2) newton(std::integral_constant<int, RMAX >= 2 ? 2 : 1>{});
-    else if (R == 3) newton(std::integral_constant<int, RMAX >= 3 ? 3 : 1>{});
-    else if (R == 4) newton(std::integral_constant<int, RMAX >= 4 ? 4 : 1>{});
-    else if (R == 5) newton(std::integral_constant<int, RMAX >= 5 ? 5 : 1>{});
-    else newton(std::integral_constant<int, RMAX >= 6 ? 6 : 1>{});
-
-    // the draw, cuda.cu:157-176
-    int sel_r = -1, sel_lane = 0, last_r = -1, last_lane = 0;
-#pragma unroll
-    for (int r = 0; r < RMAX; r++) {
-        if (r < R) {
-            const bool isS = lowhalf != ((r & 1) != 0);
-            const bool pos = in[r] && isS && term[r] > 0.f;
-            const unsigned long long hit = __builtin_amdgcn_ballot_w64(pos && x[r] >= rnd), anyp = __builtin_amdgcn_ballot_w64(pos);
-            if (sel_r < 0 && hit) { sel_r = r; sel_lane = __builtin_ctzll(hit); }
-            if (anyp) { last_r = r; last_lane = 63 - __builtin_clzll(anyp); }
-        }
-    }
-    if (sel_r < 0) { sel_r = last_r; sel_lane = last_lane; }
-    action_o = -1; child_o = -1; sel_o = 0;
-    if (sel_r >= 0) {
-        uint32_t ccs = 0;
-#pragma unroll
-        for (int r = 0; r < RMAX; r++) if (r == sel_r) ccs = (uint32_t)__builtin_amdgcn_readlane((int)cc[r], sel_lane);
-        action_o = (int)(ccs & 0xffffu);
-        sel_o = 32 * sel_r + (sel_lane & 31);
-        child_o = __builtin_amdgcn_readfirstlane((int)(int16_t)(ccs >> 16));
-    }
-}
-
-// LDS words of env e of the workgroup
-enum { EV_GO = 0,       // leader -> members: batch number << 8 | positions of the batch; EV_FIN once the descent has ended
-       EV_NREQ,         // tickets taken by joining waves (position = 2 + ticket)
-       EV_NLEV, EV_GOING, EV_B, EV_CPUCT, EV_WORDS = 8 };
-#define EV_FIN 0x7fffffff
-#define BLX_POLL_LIMIT (1 << 20)     // a wave never waits for ever: a protocol error TRAPS (the launch fails loudly at the next sync), it neither hangs the GPU nor passes wrong results on
-
-__device__ __forceinline__ int lds_peek(const int* p) {     // one broadcast LDS read, wave-uniform
-    return __builtin_amdgcn_readfirstlane(__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
-}
-// Payload before flag, flag before payload: a wave's DS operations execute in order, so all that is needed is that the COMPILER keeps
-// the order -- a workgroup-scope fence would also wait for the wave's outstanding GLOBAL stores (s_waitcnt vmcnt(0): the path[]
-// store of every level, a memory round trip per batch -- the first version of this kernel lost 3 us per launch to it).
-__device__ __forceinline__ void lds_order() { asm volatile("" ::: "memory"); }
-__device__ __forceinline__ void lds_poke(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
-
-template <int RMAX, bool FAST, int NE>
-__global__ void __launch_bounds__(BL_WAVE * 2 * NE, (RMAX <= 3 ? 8 : 4)) sim_expand4_kernel(Search s, int sim, const uint16_t* rands, int16_t* leaves_out,
-                                                                                        void* obs_out, uint8_t* valid_out, int32_t* leaf_seats_out,
-                                                                                        int deep_thresh, int help_thresh, int maxw) {
-    constexpr int W = 2 * NE;                       // waves of the workgroup = the most positions a batch can have
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    __shared__ int st_qp[NE][64], st_nn[NE][64];    // what a joining wave needs of env e's slots: normalised q (both seats) and n
-    __shared__ __attribute__((aligned(16))) int ev[NE][EV_WORDS];
-    __shared__ __attribute__((aligned(16))) int task[NE][W][4];     // leader -> position k: {node, info, uniform (f16 bits), -}
-    __shared__ __attribute__((aligned(16))) int res[NE][W][4];      // position k -> leader: {action, child, index in the row, batch number}
-    __shared__ int nfinished, wantmask;             // envs whose descent has ended; bit e: env e would take another wave
-    const int S = s.S, A = S * S, T = s.T;
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    if (threadIdx.x == 0) wantmask = 0;
-    for (int i = threadIdx.x; i < NE * EV_WORDS; i += blockDim.x) ((int*)ev)[i] = 0;
-    for (int i = threadIdx.x; i < NE * W * 4; i += blockDim.x) { ((int*)res)[i] = 0; ((int*)task)[i] = 0; }
-    if (threadIdx.x == 0) nfinished = 0;
-    __syncthreads();                                 // the only workgroup barrier: from here on envs run independently of each other
-
-    // ---- prologue: wave w belongs to env w / 2; the even wave is its leader.  Slot statistics: lane t <-> slot t; transition_q
-    // (cuda.cu:101-105) of every slot, both seats, once per launch
-    const int e0 = wave >> 1;
-    const bool leader = !(wave & 1);
-    uint32_t qp; int nn, info = 0, rd = 0, fav = -1;
-    int b0;
-    {
-        // env e of workgroup g: launch slot g + e * gridDim.x -- with gridDim.x a multiple of 8 all NE envs of a workgroup are
-        // = g (mod 8), the XCD the workgroup runs on (bl_mlp.hip forms its row tiles by env mod 8)
-        const int slot = blockIdx.x + e0 * gridDim.x;
-        int b = slot < s.B ? (s.order ? s.order[slot] : slot) : s.B;
-        if (b >= active_envs(s)) b = -1;
-        b0 = __builtin_amdgcn_readfirstlane(b);
-        const long envbase = (long)(b0 < 0 ? 0 : b0) * T;
-        uint32_t wp = 0; nn = 0;
-        if (b0 >= 0 && lane < T) {
-            wp = *(const uint32_t*)(s.w + (envbase + lane) * 2);
-            nn = s.n[envbase + lane];
-            if (leader) {
-                info = (int)(uint16_t)s.nk[envbase + lane] | ((s.seats[envbase + lane] & 1) << 16) | ((s.terminal[envbase + lane] ? 1 : 0) << 17);
-                rd = rands[envbase + lane];
-                fav = s.fav[envbase + lane];
-            }
-        }
-        float lo, hi;
-        load_qrange(s.qrange + (long)BL_QWORDS * sim, lo, hi);
-        const float rden = hi - lo + 1.e-4f;
-        const float den = (float)nn + 1.e-4f;
-        const float q0 = h2f((uint16_t)wp) / den, q1 = h2f((uint16_t)(wp >> 16)) / den;
-        qp = (uint32_t)f2h((q0 - lo) / rden) | ((uint32_t)f2h((q1 - lo) / rden) << 16);
-    }
-    int att = e0, pos = 1, lastseq = 0;                // the env this wave works for (-1: none), its position, the last batch seen
-    int ab = b0;                                       // ... that env's index and c_puct
-    float acpuct = b0 >= 0 ? h2f(s.c_puct[b0]) : 0.f;
-
-    if (leader) {
-        const int e = e0, b = b0;
-        const long envbase = (long)(b < 0 ? 0 : b) * T;
-        int16_t* path = s.path ? s.path + (long)b * (T + 2) : nullptr;
-        int t = 0, tinfo = __builtin_amdgcn_readfirstlane(info), nlev = 0, parent = 0, action = -1, sel_e = 0, seq = 0;
-        bool live = b >= 0, wants = false;
-        st_qp[e][lane] = (int)qp; st_nn[e][lane] = nn;
-        if (lane == 0) {
-            lds_poke(&ev[e][EV_B], b); lds_poke(&ev[e][EV_CPUCT], b >= 0 ? (int)s.c_puct[b] : 0); lds_poke(&ev[e][EV_NLEV], 0);
-        }
-        lds_order();
-        if (lane == 0) lds_poke(&ev[e][EV_GOING], (live && !((tinfo >> 17) & 1)) ? 1 : 0);
-        // ---- descend_kernel's loop, cuda.cu:138-182, a batch of up to `cnt` guessed levels at a time
-        for (int batch = 0; batch <= T; batch++) {
-            if (!live || t == -1 || ((tinfo >> 17) & 1) || nlev >= T) break;
-            int cnt = 2 + lds_peek(&ev[e][EV_NREQ]);
-            if (cnt > W) cnt = W;
-            {
-                // free waves look at ONE word between long sleeps: this env's bit says whether it would take another wave
-                const bool w = nlev >= help_thresh && cnt < maxw && cnt < W;
-                if (w != wants) {
-                    wants = w;
-                    if (lane == 0) {
-                        if (w) __hip_atomic_fetch_or(&wantmask, 1 << e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        else __hip_atomic_fetch_and(&wantmask, ~(1 << e), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    }
-                }
-            }
-            // the nodes of this batch: the current one and its guessed continuation
-            int u[W], uinfo[W];
-            u[0] = t; uinfo[0] = tinfo;
-#pragma unroll
-            for (int k = 1; k < W; k++) {
-                u[k] = -1; uinfo[k] = 0;
-                if (k < cnt && nlev >= deep_thresh && u[k - 1] != -1 && !((uinfo[k - 1] >> 17) & 1)) {
-                    u[k] = __builtin_amdgcn_readfirstlane(__builtin_amdgcn_readlane(fav, u[k - 1] & 63));
-                    if (u[k] != -1) uinfo[k] = __builtin_amdgcn_readfirstlane(__builtin_amdgcn_readlane(info, u[k] & 63));
-                }
-            }
-            seq++;
-#pragma unroll
-            for (int k = 1; k < W; k++) {
-                if (k < cnt) {
-                    const int rk = u[k] != -1 ? __builtin_amdgcn_readlane(rd, u[k] & 63) : 0;
-                    if (lane == 0) { task[e][k][0] = u[k]; task[e][k][1] = uinfo[k]; task[e][k][2] = rk; }
-                }
-            }
-            lds_order();
-            if (lane == 0) { lds_poke(&ev[e][EV_GO], (seq << 8) | cnt); lds_poke(&ev[e][EV_NLEV], nlev); }
-            int ra, rc, rs;
-            {
-                const float rnd = h2f((uint16_t)__builtin_amdgcn_readfirstlane(__builtin_amdgcn_readlane(rd, t & 63)));
-                evaluate_node<RMAX, FAST>(s, envbase, A, t, tinfo, rnd, acpuct, qp, nn, ra, rc, rs);
-            }
-            // follow the drawn edges through the batch; a position's result is waited for only when the walk gets there
-#pragma unroll
-            for (int k = 0; k < W; k++) {
-                if (k < cnt) {
-                    int a_k = ra, c_k = rc, s_k = rs;
-                    if (k > 0) {
-                        int polls = 0;
-                        while (lds_peek(&res[e][k][3]) != seq) { if (++polls >= BLX_POLL_LIMIT) __builtin_trap(); __builtin_amdgcn_s_sleep(1); }
-                        lds_order();
-                        a_k = lds_peek(&res[e][k][0]); c_k = lds_peek(&res[e][k][1]); s_k = lds_peek(&res[e][k][2]);
-                    }
-                    const int node = u[k];
-                    if (path && lane == 0) path[1 + nlev] = (int16_t)node;
-                    nlev++;
-                    parent = node; sel_e = s_k;
-                    if (a_k < 0) { action = -1; live = false; break; }       // no action with positive probability: the reference would index [-1]
-                    action = a_k;
-                    {
-                        // node's most visited child once this descent is backed up: the drawn child gains a visit (n += 2)
-                        const int cnew = c_k == -1 ? sim : c_k;
-                        const int f_old = __builtin_amdgcn_readfirstlane(__builtin_amdgcn_readlane(fav, node & 63));
-                        bool upd = f_old == -1;
-                        if (!upd) upd = __builtin_amdgcn_readlane(nn, cnew & 63) + 2 >= __builtin_amdgcn_readlane(nn, f_old & 63);
-                        if (upd && lane == (node & 63)) fav = cnew;
-                    }
-                    t = c_k;
-                    if (t == -1) break;
-                    tinfo = __builtin_amdgcn_readfirstlane(__builtin_amdgcn_readlane(info, t & 63));
-                    if ((tinfo >> 17) & 1) break;
-                    if (!(k + 1 < cnt && u[k + 1 < W ? k + 1 : 0] == t)) break;      // the guess ends here: next batch starts at t
-                }
-            }
-        }
-        if (lane == 0) {
-            lds_poke(&ev[e][EV_GOING], 0); lds_poke(&ev[e][EV_GO], EV_FIN);
-            if (wants) __hip_atomic_fetch_and(&wantmask, ~(1 << e), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            __hip_atomic_fetch_add(&nfinished, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        }
-        if (b >= 0) {
-            // ---- leaves = children[envs, parents, actions]; leaves[leaves == -1] = sim (mcts/__init__.py:117-122); Hex.step + observe
-            if (action < 0) action = 0;
-            if (lane < T) s.fav[envbase + lane] = (int16_t)fav;
-            uint8_t* cells = (uint8_t*)smem + (size_t)e * al16(A);
-            const int nxt = t;
-            const int leaf = (nxt == -1) ? sim : nxt;
-            if (s.lazy) lazy_slot_reset(s, envbase, sim, A, nxt == -1, lane);
-            if (lane == 0) {
-                s.children[(envbase + parent) * A + action] = (int16_t)leaf;
-                s.parents[envbase + leaf] = (int16_t)parent;
-                s.relation[envbase + leaf] = (int16_t)action;
-                if (nxt == -1 && nlev > 0) ((uint16_t*)(s.cca + (envbase + parent) * A + sel_e))[1] = (uint16_t)leaf;   // the compacted row's child field
-            }
-            const int seat = s.seats[envbase + parent];
-            const uint8_t* src = s.boards + (envbase + parent) * A;
-            for (int a = lane; a < A; a += 64) cells[a] = src[a];
-            board_sync<true>();
-            const int win = hex_step_group<64, true>(cells, S, seat, action, true, lane);
-            const bool term = win != 0;                                          // Hex.step tail, hex/__init__.py:183-190
-            const int new_seat = term ? 0 : 1 - seat;
-            uint8_t* dst = s.boards + (envbase + leaf) * A;
-            const float invS = 1.0f / (float)S;
-            const bool flip = new_seat == 1;
-            for (int a = lane; a < A; a += 64) dst[a] = term ? (uint8_t)0 : cells[a];
-            for (int a = lane; a < A; a += 64) {
-                const int i = (int)(((float)a + 0.5f) * invS), j = a - i * S;
-                const int color = term ? 2 : color_of(cells[flip ? j * S + i : a]);
-                const int ch = color < 2 ? (flip ? 1 - color : color) : 2;
-                if (s.obs_f16) ((uint32_t*)obs_out)[(long)b * A + a] = ch == 0 ? 0x00003c00u : (ch == 1 ? 0x3c000000u : 0u);   // f16 1.0 = 0x3c00
-                else ((float2*)obs_out)[(long)b * A + a] = make_float2(ch == 0 ? 1.f : 0.f, ch == 1 ? 1.f : 0.f);
-                valid_out[(long)b * A + a] = color == 2;
-            }
-            if (lane == 0) {
-                s.seats[envbase + leaf] = new_seat;
-                s.terminal[envbase + leaf] = term;
-                s.rewards[(envbase + leaf) * 2 + 0] = f2h((float)win);
-                s.rewards[(envbase + leaf) * 2 + 1] = f2h((float)(-win));
-                leaves_out[b] = (int16_t)leaf;
-                leaf_seats_out[b] = new_seat;
-                if (path) {
-                    path[1 + nlev] = (int16_t)leaf;
-                    path[0] = (int16_t)(nlev + 1);
-                }
-            }
-        }
-        att = -1;                                     // the leader is free now, too
-    }
-
-    // ---- a member's life: serve the env it is attached to until that ends, then join another one of the workgroup that still goes
-    for (int polls = 0; polls < BLX_POLL_LIMIT; polls++) {
-        if (att >= 0) {
-            const int g = lds_peek(&ev[att][EV_GO]);
-            if (g == EV_FIN) { att = -1; continue; }
-            const int sq = g >> 8, cnt = g & 0xff;
-            if (sq == lastseq) { __builtin_amdgcn_s_sleep(1); continue; }
-            lastseq = sq;
-            if (pos >= cnt) continue;                 // joined after this batch was laid out
-            lds_order();
-            const int node = lds_peek(&task[att][pos][0]), ninfo = lds_peek(&task[att][pos][1]), rbits = lds_peek(&task[att][pos][2]);
-            if (lds_peek(&ev[att][EV_GO]) != g) { lastseq = sq - 1; continue; }     // the leader has moved on meanwhile: read again
-            int ra = -2, rc = -1, rs = 0;
-            if (node != -1 && !((ninfo >> 17) & 1)) evaluate_node<RMAX, FAST>(s, (long)ab * T, A, node, ninfo, h2f((uint16_t)rbits), acpuct, qp, nn, ra, rc, rs);
-            if (lane == 0) { res[att][pos][0] = ra; res[att][pos][1] = rc; res[att][pos][2] = rs; }
-            lds_order();
-            if (lane == 0) lds_poke(&res[att][pos][3], sq);
-            polls = 0;
-        } else {
-            if (lds_peek(&nfinished) >= NE) return;
-            const int want = lds_peek(&wantmask);
-            if (!want) { __builtin_amdgcn_s_sleep(32); continue; }      // nothing to do: ~2k cycles asleep per look, next to no issue slots
-            // among the envs that would take a wave (at or beyond level help_thresh, below maxw waves): the fewest waves, the deepest among equals
-            int best = -1, bestcnt = 0, bestlev = 0;
-#pragma unroll
-            for (int e = 0; e < NE; e++) {
-                if ((want >> e) & 1) {
-                    const int going = lds_peek(&ev[e][EV_GOING]), lev = lds_peek(&ev[e][EV_NLEV]), c = 2 + lds_peek(&ev[e][EV_NREQ]);
-                    if (going && c < maxw && c < W && (best < 0 || c < bestcnt || (c == bestcnt && lev > bestlev))) { best = e; bestcnt = c; bestlev = lev; }
-                }
-            }
-            if (best < 0) { __builtin_amdgcn_s_sleep(8); continue; }
-            // the batch number BEFORE the ticket: every later batch that counts this position in is served
-            const int g = lds_peek(&ev[best][EV_GO]);
-            if (g == EV_FIN) continue;
-            lastseq = g >> 8;
-            int ticket = 0;
-            if (lane == 0) ticket = __hip_atomic_fetch_add(&ev[best][EV_NREQ], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            ticket = __builtin_amdgcn_readfirstlane(ticket);
-            att = best; pos = 2 + ticket;
-            lds_order();
-            qp = (uint32_t)st_qp[att][lane]; nn = st_nn[att][lane];
-            ab = lds_peek(&ev[att][EV_B]); acpuct = h2f((uint16_t)lds_peek(&ev[att][EV_CPUCT]));
-            if (pos >= W) att = -1;                   // cannot happen (a workgroup has W - 2 waves besides an env's own two)
-        }
-    }
-    __builtin_trap();                                 // the poll budget ran out: a protocol error
-}
+// (Round 4's shared-workgroup kernel -- several envs per workgroup, the waves of finished descents helping the ones still going --
+// was bit-exact and slower at every batch size (profiles/r04_shared_wg_*.txt, HISTORY.md); it was removed in round 5: its
+// protocol trapped on an exhausted poll budget, which aborts the HIP context, and nothing used it.  bl_tune_t.expand_envs > 1 is
+// now BL_EINVAL.)
 
 // ------------------------------------------------------------------------------------------------------------------
 // Two nodes per wave.  While every env still descends, the kernel is bound by VALU issue (4.3 k VALU instructions per env,
@@ -1198,19 +809,8 @@ int bl_expand2_launch(const Search& ss, int sim, const void* rands, int16_t* lea
                       unsigned long long* counters, int fast, int waves, int deep_thresh, int envs, int help_thresh, hipStream_t stream) {
     const int A = ss.S * ss.S, T = ss.T;
     if (!ss.cpi || !ss.cca || !ss.nk || A > 384 || T > 256) return BL_ETOOBIG;
-    if ((envs == 2 || envs == 4) && ss.fav && A <= 192 && T <= 64 && !counters && !ss.powf_libm) {
-        // envs per workgroup, two waves each, finished envs' waves help the ones still going (sim_expand4_kernel)
-        const dim3 grid4((ss.B + envs - 1) / envs), block4(64 * 2 * envs);
-        const size_t lds4 = (size_t)al16(A) * envs;
-#define BLX4(R_, NE_) { if (fast) hipLaunchKernelGGL((sim_expand4_kernel<R_, true, NE_>), grid4, block4, lds4, stream, ss, sim, (const uint16_t*)rands, leaves, obs, valid, leaf_seats, deep_thresh, help_thresh & 0xff, ((help_thresh >> 8) & 0xff) ? ((help_thresh >> 8) & 0xff) : 2 * NE_); \
-                        else hipLaunchKernelGGL((sim_expand4_kernel<R_, false, NE_>), grid4, block4, lds4, stream, ss, sim, (const uint16_t*)rands, leaves, obs, valid, leaf_seats, deep_thresh, help_thresh & 0xff, ((help_thresh >> 8) & 0xff) ? ((help_thresh >> 8) & 0xff) : 2 * NE_); }
-#define BLX4E(R_) { if (envs == 2) BLX4(R_, 2) else BLX4(R_, 4) }
-        const int need4 = (A + 31) / 32;
-        if (need4 <= 1) BLX4E(1) else if (need4 <= 2) BLX4E(2) else if (need4 <= 3) BLX4E(3) else BLX4E(6)
-#undef BLX4E
-#undef BLX4
-        return hipGetLastError() == hipSuccess ? BL_OK : BL_ELAUNCH;
-    }
+    if (envs > 1) return BL_EINVAL;       // the shared-workgroup kernel of round 4 is gone (see above)
+    (void)help_thresh;
     if (waves == 21 && ss.fav && A <= 96 && T <= 64 && !counters && !ss.powf_libm) {
         // two nodes per wave (sim_expand3_kernel)
         const dim3 grid3(ss.B), block3(64);

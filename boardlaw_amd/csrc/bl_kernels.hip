@@ -1310,7 +1310,6 @@ static int check_launch() { return hipGetLastError() == hipSuccess ? BL_OK : BL_
 int bl_expand2_launch(const Search& ss, int sim, const void* rands, int16_t* leaves, void* obs, uint8_t* valid, int32_t* leaf_seats,
                       unsigned long long* counters, int fast, int waves, int deep_thresh, int envs, int help_thresh, hipStream_t stream);     // bl_expand.hip
 int bl_fold_selftest(int use_fast, hipStream_t stream);
-#define BL_EXPAND_ENVS_DEFAULT 1        // until the A/B of round 4 says otherwise
 
 namespace bl {
 __global__ void __launch_bounds__(256) powf2_kernel(const float* x, float* out, long n) {
@@ -1513,9 +1512,8 @@ static int sim_expand_impl(const bl_search_t* s, int sim, const void* rands, int
         // waves per env: two fill the chip's 8192 wave slots at 4096 envs; up to 1024 envs four fit twice over and a batch then
         // covers four guessed levels (13x13, 1024 envs x 256 sims: 44.2 -> 40.3 ms per move; 9x9 at 2048 envs: no gain, at 4096 a loss)
         const int waves = tune.expand_waves ? tune.expand_waves : (s->B <= 1024 ? 4 : 2);
-        // envs per workgroup (round 4): the waves of an env whose descent has ended help the envs of their workgroup that still go
-        // (T <= 64, boards up to 13x13; see sim_expand4_kernel).  expand_envs 1 = one env per workgroup (the round-2 kernel)
-        const int envs = tune.expand_envs ? tune.expand_envs : BL_EXPAND_ENVS_DEFAULT;
+        // (expand_envs > 1 was round 4's shared-workgroup kernel: removed, BL_EINVAL)
+        const int envs = tune.expand_envs ? tune.expand_envs : 1;
         rc = bl_expand2_launch(to_search(s), sim, rands, leaves, obs, valid, leaf_seats, counters, tune.fold_fast != 0,
                                waves, tune.expand_deep, tune.expand_waves ? 1 : envs, tune.expand_help, (hipStream_t)stream);
         if (rc != BL_ETOOBIG) return rc;

@@ -516,14 +516,17 @@ class MCTSAgent:
         self.pad = pad
         self._graphs = {}           # insertion-ordered: oldest use first
 
-    # A padded replay equals the eager call on the same envs because torch's Dirichlet / uniform kernels give element i the same
-    # number whatever the tensor's size -- true while one launch covers the tensor with one element per thread, i.e. up to
-    # CUs x 2048 threads (torch_rand_geometry: `loops` == 1).  Above that the grid-stride loop maps counters to elements by the
-    # grid size, so padding is switched off there (the move is captured for exactly n envs).
-    def _pad_keeps_the_stream(self, cap, world):
-        props = torch.cuda.get_device_properties(world.device)
-        threads = props.multi_processor_count * (props.max_threads_per_multi_processor // 256) * 256
-        return cap * int(np.prod(world.action_space)) <= threads
+    # A padded replay equals the eager call on the same envs because torch's random kernels give element i the same number
+    # whatever the tensor's size: the uniform / exponential kernels hand element i to thread i % threads, Philox block
+    # i // (4 threads), component (i // threads) % 4 -- with `threads` either covering the tensor (one element per thread) or
+    # capped at the chip's CUs x 2048, the same cap for every size -- and the gamma kernel keeps one curand state per thread,
+    # walked in grid-stride order.  What DOES depend on the size is how far a call advances the generator: 4 x `loops`
+    # (torch_rand_geometry).  So a move may be padded from n to cap rows iff every random tensor of the move -- (rows, A) for the
+    # Dirichlet and the action draw, (rows, T) for the descents -- has the same `loops` at both sizes.  (Round 4 tested
+    # cap x A <= threads, which switched padding off from 2049 envs at 13x13 and ignored the (rows, T) block: advisor finding.)
+    def _pad_keeps_the_stream(self, n, cap, world):
+        A, T = int(np.prod(world.action_space)), int(self.kwargs.get('n_nodes', 64))
+        return all(torch_rand_geometry(n * x, world.device)[1] == torch_rand_geometry(cap * x, world.device)[1] for x in (A, T))
 
     def _capacity(self, n, world=None):
         if not self.pad:
@@ -531,7 +534,7 @@ class MCTSAgent:
         cap = self.MIN_CAPACITY
         while cap < n:
             cap *= 2
-        if world is not None and not (cap == n or self._pad_keeps_the_stream(cap, world)):
+        if world is not None and not (cap == n or self._pad_keeps_the_stream(n, cap, world)):
             return n
         return cap
 

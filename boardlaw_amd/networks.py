@@ -160,7 +160,12 @@ class Inference:
 
     def refresh_if_stale(self):
         """refresh() only if a parameter was modified in place (optimiser step, load_state_dict) or replaced since the
-        last refresh.  Host-side check of tensor version counters: no device work when nothing changed."""
+        last refresh.  Host-side check of tensor version counters: no device work when nothing changed.
+        With PERSIST_PLAN (off by default) this is also where the one-launch kernel's error word is read -- once per move, before
+        the next one is issued: a forward whose bounded waits ran out has written invalid logits, and the search must not go on."""
+        if self.PERSIST_PLAN and self._persist and not torch.cuda.is_current_stream_capturing() and self.persist_error():
+            raise RuntimeError('bl_mlp_layers_persist_f16: a bounded wait ran out (peers of a row tile were kept off the chip, e.g. by '
+                               'another stream); the forwards since the last check are invalid -- use the launch-per-Linear plan')
         if self._static is None or self._stamp() != self._stamped:
             self.refresh()
 

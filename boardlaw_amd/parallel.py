@@ -146,7 +146,14 @@ class GradientBucket:
     (round-3 verdict: at 1024x8 the cat/copy form was three extra passes over 35 MB and ~40 launches per step).  The same idea as
     DDP's gradient_as_bucket_view, with one bucket: FCModel is at most 17.9 M parameters, latency- not bandwidth-bound on xGMI.
 
-    Use `bucket.zero()` instead of `opt.zero_grad()` (which would drop the views), then backward, then `bucket.allreduce()`."""
+    Use `bucket.zero()` instead of `opt.zero_grad()` (which would drop the views), then backward, then `bucket.allreduce()`.
+
+    Every parameter keeps a (zero) .grad for good, so the optimiser steps ALL of them every time -- Adam's moments decay and weight
+    decay applies even to a parameter autograd never reached, where `zero_grad(set_to_none=True)` would have skipped it.  FCModel's
+    losses reach every parameter (policy + value heads on one body; a ReZero block behind alpha = 0 gets an all-zero gradient TENSOR,
+    not None, with or without the bucket), so for this path the two are the same optimiser step (tests/test_training.py compares them)."""
+
+    MAX_EVENTS = 4096           # timed=True keeps the last MAX_EVENTS collectives' event pairs, not all of a long run's
 
     def __init__(self, module, always=False, timed=False):
         """always: run the collective in a one-rank group, too (benchmarks of the code path); timed: bracket every collective with
@@ -187,6 +194,7 @@ class GradientBucket:
         if timed:
             b.record()
             self.events.append((a, b))
+            del self.events[:-self.MAX_EVENTS]
 
     def collective_ms(self):
         """Device time of every timed all-reduce + scaling so far (synchronises)."""

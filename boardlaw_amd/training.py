@@ -93,11 +93,12 @@ def run(worlds, network, n_steps, nodes=64, c_puct=1 / 16, lr=1e-3, buffer_len=6
     opt = torch.optim.Adam(network.parameters(), lr=lr)
     scaler = torch.amp.GradScaler('cuda', enabled=(dev.type == 'cuda'))
     # several ranks: the gradients live in one flat buffer that is all-reduced where it lies (parallel.GradientBucket)
-    bucket = parallel.GradientBucket(network) if (torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1) else None
-    if timings is not None and torch.distributed.is_initialized():
-        # under the benchmark: the same code path in a one-rank group, too, every collective bracketed by device events
-        bucket = parallel.GradientBucket(network, always=True, timed=True)
-        timings['bucket'] = bucket
+    # (built ONCE; under the benchmark the same code path runs in a one-rank group, too, every collective bracketed by device events)
+    bucket = None
+    if torch.distributed.is_initialized() and (timings is not None or torch.distributed.get_world_size() > 1):
+        bucket = parallel.GradientBucket(network, always=timings is not None, timed=timings is not None)
+        if timings is not None:
+            timings['bucket'] = bucket
     idxs = [(torch.randint(buffer_len, (w.n_envs,), device=dev), torch.arange(w.n_envs, device=dev)) for w in batches]
     buffers = [[] for _ in batches]
 

@@ -50,12 +50,10 @@ typedef struct {
                           if the simulation creates no node also logits[b,sim,:] = NaN and the root board in boards[b,sim]).  After
                           all T-1 simulations every array equals the eager reset's; before that, slots > sim are undefined: for
                           callers that always run a whole search (MCTSAgent) */
-    int expand_envs;   /* envs per workgroup in bl_sim_expand (T <= 64): 0 = default; 1 = one (two or four waves of its own per env);
-                          2 / 4 = that many, two waves each, and the waves of an env whose descent has ended join the envs of their
-                          workgroup that still go (batches of 4..8 guessed levels for exactly the long descents).  Ignored when
-                          expand_waves is set */
-    int expand_help;   /* with expand_envs 2 / 4: free waves join an env only from this descent level on (low byte; default 0), up to
-                          this many waves per env (next byte; default all) */
+    int expand_envs;   /* reserved (ABI 3 layout kept): round 4's shared-workgroup bl_sim_expand -- 2 / 4 envs per workgroup, the waves
+                          of finished descents helping the ones still going; bit-exact, slower at every batch size -- was removed in
+                          round 5.  0 or 1; anything else makes bl_sim_expand return BL_EINVAL */
+    int expand_help;   /* reserved (was: the shared-workgroup kernel's help threshold); ignored */
     int powf_libm;     /* NOT a tuning choice but a second parity target: 1 = the Newton derivative term divides by glibc's
                           powf(bot, 2) (what the reference's own JIT build computes: no -O flag, boardlaw/cuda.py:29-45,
                           boardlaw/mcts/cpp/cpu.cpp:60) instead of bot * bot (what g++ -O1 and up make of it; the default).  The two

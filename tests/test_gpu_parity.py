@@ -1,6 +1,7 @@
 """GPU parity: the HIP path (through the C ABI of libboardlaw_amd.so) against the CPU oracle and the reference's
 golden vectors.  Bit-exact: every integer, byte, index and binary16 output must be identical (tolerance = 0).
 Run on an MI355X with `pytest -m gpu`."""
+import ctypes
 import os
 
 import numpy as np
@@ -672,22 +673,17 @@ def test_two_nodes_per_wave_expand_in_subprocess():
     assert ' passed' in r.stdout
 
 
-@pytest.mark.parametrize('envs,help_from', [(2, 0), (4, 0), (4, 3), (1, 0)])
-def test_shared_workgroup_expand_in_subprocess(envs, help_from):
-    """bl_expand.hip's sim_expand4_kernel (round 4: `envs` envs per workgroup, two waves each, the waves of a finished descent
-    joining the envs of their workgroup that still go -- batches of up to 2 * envs guessed levels) and the one-env-per-workgroup
-    kernel it replaces as the default (BL_EXPAND_ENVS=1): whichever is the default, both must pass the same oracle comparisons
-    bit for bit -- per-op goldens are not enough here, the batches' hand-over is what differs, so whole searches are replayed."""
-    import subprocess, sys
-    env = dict(os.environ, BL_EXPAND_ENVS=str(envs), BL_EXPAND_HELP=str(help_from))
-    here = os.path.dirname(os.path.abspath(__file__))
-    r = subprocess.run([sys.executable, '-m', 'pytest', os.path.join(here, 'test_gpu_parity.py'), '-q', '-x', '-m', 'gpu',
-                        '-k', '(test_whole_search_replay and fused) or (test_full_size_search_vs_oracle and not 13-96) or '
-                              '(test_bench_launch_sequence_vs_oracle and 9-4096-64-512-4) or test_search_with_per_env_c_puct or '
-                              'test_masked_search or n_active'],
-                       env=env, capture_output=True, text=True, timeout=1200)
-    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-    assert ' passed' in r.stdout
+def test_removed_shared_workgroup_expand_is_refused():
+    """Round 4's shared-workgroup bl_sim_expand (bl_tune_t.expand_envs = 2 / 4) was removed in round 5 (bit-exact, slower, and its
+    protocol trapped on an exhausted poll budget): the field is reserved and any value but 0 / 1 is BL_EINVAL, not a silent default."""
+    from boardlaw_amd import _native
+    from boardlaw_amd.hex import Hex
+    from boardlaw_amd.mcts import MCTS
+    m = MCTS(Hex.initial(8, 5, device=DEV), n_nodes=4)
+    m._search.tune.expand_envs = 2
+    z = torch.zeros(8 * 64, dtype=torch.int32, device=DEV)
+    rc = _native.lib().bl_sim_expand(ctypes.byref(m._search), 1, z.data_ptr(), z.data_ptr(), z.data_ptr(), z.data_ptr(), z.data_ptr(), _native.stream(m.device))
+    assert rc == _native.BL_EINVAL
 
 
 # ------------------------------------------------------------------------------------------------ widened rows (SURVEY 8f)

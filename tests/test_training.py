@@ -341,26 +341,34 @@ def test_chunk_evaluator_with_search_agents():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('S,n', [(9, 1000), (9, 777), (7, 64), (9, 2048), (5, 3)])
-def test_masked_captured_move_equals_the_eager_masked_call(S, n):
+@pytest.mark.parametrize('S,n,pool,T', [(9, 1000, 2048, 32), (9, 777, 2048, 32), (7, 64, 2048, 32), (9, 2048, 2048, 32), (5, 3, 2048, 32),
+                                        (13, 2100, 4096, 16), (3, 17000, 32768, 100)])
+def test_masked_captured_move_equals_the_eager_masked_call(S, n, pool, T):
     """One move captured for a capacity bucket (2048 / 1024 / 64 rows) serves a call of n envs with the other rows switched off
     on the device (bl_search_t.n_active): decisions identical, bit for bit, to the eager call on exactly those n envs under the
     same seed -- same Dirichlet rows, same uniforms (torch's kernels give row i the same numbers whatever the batch size), and a
-    q-range over the n envs only.  Twice in a row: the second replay reuses the capture with another n."""
+    q-range over the n envs only.  Twice in a row: the second replay reuses the capture with another n.
+    (13, 2100): the padded tensors are beyond the size torch's random kernels cover with one element per thread (4096 x 169 > CUs x
+    2048) and the eager ones are not -- the rows' numbers are still the same, so the move is padded (round-4 advisor finding).
+    (3, 17000) with 100 nodes: the (rows, T) block of a 32768-row capture would advance the generator by two Philox rounds where the
+    eager call advances it by one -- MCTSAgent._pad_keeps_the_stream refuses the padding and captures for exactly n rows."""
     from boardlaw_amd import networks
     from boardlaw_amd.hex import Hex
     from boardlaw_amd.mcts import MCTSAgent, MoveRng
     from test_reference_fixtures import EdgeAgent
     torch.manual_seed(S)
-    worlds = Hex.initial(2048, S)
+    worlds = Hex.initial(pool, S)
     for k in range(S * S // 3):                                   # mid-game positions, different per env
         v = worlds.valid
         worlds, _ = worlds.step((torch.rand(v.shape, device='cuda') * v).argmax(-1))
     net = networks.Inference(networks.FCModel(worlds.obs_space, worlds.action_space, width=256, depth=2).cuda(), fused=True)
-    eager = MCTSAgent(net, n_nodes=32, rng=MoveRng())
-    graphed = MCTSAgent(net, n_nodes=32, rng=MoveRng(), graph=True)
+    eager = MCTSAgent(net, n_nodes=T, rng=MoveRng())
+    graphed = MCTSAgent(net, n_nodes=T, rng=MoveRng(), graph=True)
+    if pool > 2048:
+        padded = graphed._capacity(n, worlds[:n]) != n
+        assert padded == (S == 13), (S, n, graphed._capacity(n, worlds[:n]))
     for m in (n, max(1, n // 2 + 1)):
-        sub = worlds[torch.randperm(2048, device='cuda')[:m]]
+        sub = worlds[torch.randperm(pool, device='cuda')[:m]]
         for ev in (True, False):
             torch.manual_seed(100 + m); a = eager(sub, eval=ev)
             torch.manual_seed(100 + m); b = graphed(sub, eval=ev)

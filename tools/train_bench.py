@@ -75,7 +75,7 @@ def main():
     ap.add_argument('--nodes', type=int, default=256)
     ap.add_argument('--width', type=int, default=1024)
     ap.add_argument('--depth', type=int, default=8)
-    ap.add_argument('--buffer', type=int, default=8, help='moves of self-play per learner step (the reference keeps 64 and drops B/batch per step)')
+    ap.add_argument('--buffer', type=int, default=8, help='moves the buffer holds (the reference: 64); after the first fill every learner step follows ONE new move')
     args = ap.parse_args()
     respawn(args)
     if os.environ.get('TRAIN_DRY') == '1':
@@ -113,13 +113,16 @@ def main():
         print(json.dumps({
             'metric': 'train_bench', 'n_gpus': world, 'ranks_seen': seen, 'per_rank_sims_per_sec': per_rank, 'backend': torch.distributed.get_backend(),
             'config': {'workload': f'{args.boardsize}x{args.boardsize} Hex, {args.envs} envs/rank x {args.nodes} sims/move, FCModel {args.width}x{args.depth}, '
-                                   f'learner step every {args.buffer} moves' + (' (BASELINE config 4 per-GPU shape)' if (args.boardsize, args.envs, args.nodes, args.width, args.depth) == (13, 1024, 256, 1024, 8) else '')},
+                                   f'buffer of {args.buffer} moves, 1 new move per learner step once it is full (the reference\'s main.py semantics: as_chunk drops batch_size/B = 1 step)' + (' (BASELINE config 4 per-GPU shape)' if (args.boardsize, args.envs, args.nodes, args.width, args.depth) == (13, 1024, 256, 1024, 8) else '')},
             # by learner step: the first carries the moves' graph capture and warm-up, the later ones are the steady rate
             'selfplay_ms_per_move_by_step': [round(1e3 * t / max(m, 1), 3) for t, m in zip(timings['selfplay_s'], timings['moves'])],
             'selfplay_ms_per_move': round(1e3 * timings['selfplay_s'][-1] / max(timings['moves'][-1], 1), 3), 'moves': moves,
             'learner_step_ms': [round(1e3 * x, 3) for x in timings['learner_s']],
             'allreduce_ms': [round(x, 3) for x in ar], 'bucket_mb': round(timings['bucket'].flat.numel() * 4 / 2**20, 2),
+            # whole job = including graph capture, warm-up and the first (slow) learner step; steady state = learner steps 1.. only
             'sims_per_sec_whole_job': args.envs * args.nodes * moves * world / elapsed, 'elapsed_s': elapsed,
+            'sims_per_sec_steady_state': (args.envs * args.nodes * world * sum(timings['moves'][1:]) / max(sum(timings['selfplay_s'][1:]) + sum(timings['learner_s'][1:]), 1e-9)
+                                          if len(timings['moves']) > 1 else None),
             'weights_identical_over_ranks': lo == hi}))
     torch.distributed.destroy_process_group()
 
