@@ -52,6 +52,7 @@ SYMBOLS = {
     'bl_mlp_forward_f16': (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     'bl_mlp_layers_f16': (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     'bl_mlp_layers_persist_f16': (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
+    'bl_mlp_layers_xcd_f16': (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
     'bl_root_mlp_f32': (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     'bl_sim_infer_finish': (_i, [ctypes.POINTER(Search), _i] + [_vp] * 11 + [_i] * 4 + [_vp]),
     'bl_sim_root': (_i, [ctypes.POINTER(Search), _i, _vp, _vp, _vp, _vp]),

@@ -887,6 +887,8 @@ struct PersistArgs {
     int* counters;                    // [rowtiles][nlayers] arrivals + one word: workgroups finished
     int* error;                       // set to 1 when a bounded wait ran out
     int xcd;
+    int local;                        // 1: the XCD-local protocol (layers_persist_kernel, round 5): counters = [rowtiles][nlayers][8] flags +
+                                      // 8 tickets + one word: workgroups finished
 };
 
 __global__ void __launch_bounds__(256) zero_words_kernel(int* p, int n) {
@@ -910,20 +912,78 @@ struct RowTileWait {
     }
 };
 
+// The XCD-local protocol's wait: lanes 0 .. want-1 of wave 0 each poll ONE flag -- the word column group c of this row tile stored
+// (plain, after its rows) when it had finished the previous layer -- with L1-bypassing loads: producer and poller share an XCD, so
+// the word and the rows behind it are in the L2 both sides use.
+struct RowTileFlags {
+    static constexpr bool early = true;
+    const int* flags; int want; int* error;
+    __device__ __forceinline__ void operator()() const {
+        if ((int)threadIdx.x < want) {
+            int polls = 0;
+            while (__hip_atomic_load(flags + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+                if (++polls > BLM_SPIN_LIMIT) { __hip_atomic_store(error, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+                __builtin_amdgcn_s_sleep(1);
+            }
+        }
+        __syncthreads();
+    }
+};
+
+// Round 5, `p.local`: the hand-off between two layers stays inside ONE XCD's L2.  Round 4's protocol above is placement-independent:
+// rows as write-through (`sc1`) stores, a device-scope counter per row tile and layer, L1-bypassing loads -- which drops every row
+// from the producer's L2 and brings it back at the cross-XCD rate even when, as always, the eight workgroups of a row tile DO share
+// an XCD (91.9 us per forward against 80.8 for a launch per Linear).  Here a workgroup ASKS where it runs (s_getreg HW_REG_XCC_ID),
+// takes a ticket from that XCD's counter and works on row tile xcd + 8 (ticket / ncol), column group ticket % ncol: the peers of
+// a row tile share an L2 by construction, not by an assumed dispatch order.  So the rows are plain stores (they stay in that L2),
+// `s_waitcnt vmcnt(0)` = acknowledged by it, a barrier, then the workgroup's flag word as a plain store; the peers poll the flags
+// and read the rows with L1-bypassing loads, served by the same L2.  No device-scope atomic and no write-through on the path.
+// What it needs of the dispatcher: every XCD receives (its row tiles) x ncol workgroups of the grid -- the hardware deals a grid's
+// workgroups to the XCDs in turn, and the grid is 8 x ceil(rowtiles / 8) x ncol.  An XCD that received more leaves the surplus
+// idle and one that received fewer cannot finish a row tile: its peers' bounded waits run out and raise `error` (wrong results
+// the host sees, never a hang), exactly as when a peer is kept off the chip.
 template <int RDB, int KBCB>
 __global__ void __launch_bounds__(256) layers_persist_kernel(const PersistArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     uint16_t* R = (uint16_t*)smem;
     const int tid = threadIdx.x;
     int rowtile, colgroup;
-    if (p.xcd) {
+    if (p.local) {
+        __shared__ int ticket[2];
+        if (tid == 0) {
+            int xcc;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            xcc &= 7;
+            ticket[0] = xcc;
+            ticket[1] = __hip_atomic_fetch_add(p.counters + (long)p.rowtiles * p.nlayers * 8 + xcc, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+        rowtile = ticket[0] + 8 * (ticket[1] / p.ncol); colgroup = ticket[1] % p.ncol;
+    } else if (p.xcd) {
         const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
         rowtile = xcd + 8 * (slot / p.ncol); colgroup = slot % p.ncol;
     } else {
         rowtile = blockIdx.x / p.ncol; colgroup = blockIdx.x % p.ncol;
     }
-    int* done = p.counters + (long)p.rowtiles * p.nlayers;
-    if (rowtile < p.rowtiles) {
+    int* done = p.counters + (p.local ? (long)p.rowtiles * p.nlayers * 8 + 8 : (long)p.rowtiles * p.nlayers);
+    if (p.local) {
+        if (rowtile < p.rowtiles) {
+            int* mine = p.counters + (long)rowtile * p.nlayers * 8;
+            for (int l = 0; l < p.nlayers; l++) {
+                const LayerArgs& a = p.layer[l];
+                const RowTileFlags wait{mine + (l > 0 ? l - 1 : 0) * 8, l > 0 ? p.layer[l - 1].ncol : 0, p.error};
+                if (colgroup < a.ncol) {
+                    if (l == 0) layer_body<3, 0>(a, rowtile, colgroup, R, NoWait{});
+                    else layer_body<RDB, KBCB>(a, rowtile, colgroup, R, wait);
+                }
+                if (l + 1 < p.nlayers) {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's rows are in the XCD's L2 ...
+                    __syncthreads();                                      // ... and so are the other waves' (and nobody still reads R)
+                    if (tid == 0 && colgroup < a.ncol) __hip_atomic_store(mine + l * 8 + colgroup, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+            }
+        }
+    } else if (rowtile < p.rowtiles) {
         int* mine = p.counters + (long)rowtile * p.nlayers;
         for (int l = 0; l < p.nlayers; l++) {
             const LayerArgs& a = p.layer[l];
@@ -939,14 +999,18 @@ __global__ void __launch_bounds__(256) layers_persist_kernel(const PersistArgs p
             }
         }
     }
-    // the last workgroup out zeroes the counters for the next forward
+    // the last workgroup out zeroes the counters for the next forward (write-through stores: the words were last written by other
+    // XCDs and are next read by them; all 256 threads: a write-through dword is one fabric write each)
+    __shared__ int last;
     __syncthreads();
-    if (tid == 0) {
-        const int total = gridDim.x;
-        if (__hip_atomic_fetch_add(done, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == total - 1) {
-            for (long i = 0; i < (long)p.rowtiles * p.nlayers; i++) p.counters[i] = 0;
-            __hip_atomic_store(done, 0, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-        }
+    if (tid == 0) last = __hip_atomic_fetch_add(done, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - 1;
+    __syncthreads();
+    if (last) {
+        const long words = p.local ? (long)p.rowtiles * p.nlayers * 8 + 8 : (long)p.rowtiles * p.nlayers;
+        for (long i = tid; i < words; i += 256) __hip_atomic_store(p.counters + i, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) __hip_atomic_store(done, 0, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
@@ -1055,21 +1119,21 @@ extern "C" int bl_mlp_layers_f16(const void* obs, int M, int K0, const void* w0,
     return hipGetLastError() == hipSuccess ? BL_OK : BL_ELAUNCH;
 }
 
-extern "C" int bl_mlp_layers_persist_f16(const void* obs, int M, int K0, const void* w0, const void* b0, const void* wb,
-                                         const void* bb, const float* alphas, const void* wh, const void* bh, int W, int D,
-                                         int K0pad, int NH, int NHpad, void* scratch, int* counters, int zero_first, int* error,
-                                         void* policy_out, void* value_out, bl_stream_t stream) {
+static int layers_persist_launch(const void* obs, int M, int K0, const void* w0, const void* b0, const void* wb,
+                                 const void* bb, const float* alphas, const void* wh, const void* bh, int W, int D,
+                                 int K0pad, int NH, int NHpad, void* scratch, int* counters, int zero_first, int* error,
+                                 void* policy_out, void* value_out, int local, bl_stream_t stream) {
     using namespace blmlp;
     if (!policy_out || !value_out || !scratch || !counters || !error) return BL_EINVAL;
     if (int rc = mlp_check(obs, M, K0, w0, b0, wb, bb, alphas, wh, bh, W, D, K0pad, NH, NHpad)) return rc;
     if ((K0 & 1) != 0) return BL_EINVAL;
     if (D + 2 > BLM_MAX_LAYERS || (W != 256 && W != 512 && W != 768 && W != 1024)) return BL_ETOOBIG;
     PersistArgs p;
-    p.nlayers = D + 2; p.rowtiles = (M + 31) / 32; p.ncol = W / 128; p.counters = counters; p.error = error; p.xcd = M >= 512;
+    p.nlayers = D + 2; p.rowtiles = (M + 31) / 32; p.ncol = W / 128; p.counters = counters; p.error = error; p.xcd = local || M >= 512; p.local = local;
     const unsigned grid = p.xcd ? 8u * ((p.rowtiles + 7) / 8) * p.ncol : (unsigned)p.rowtiles * p.ncol;
     if (grid > 256) return BL_ETOOBIG;          // every workgroup must find a CU while its row tile's peers run: see layers_persist_kernel
     uint16_t* buf[2] = {(uint16_t*)scratch, (uint16_t*)scratch + (size_t)M * W};
-    auto set = [&](int i, LayerArgs a) { a.ncol = (a.N / 32 + 3) / 4; a.xcd = p.xcd; a.sc1_out = a.Y != nullptr; p.layer[i] = a; };
+    auto set = [&](int i, LayerArgs a) { a.ncol = (a.N / 32 + 3) / 4; a.xcd = p.xcd; a.sc1_out = !local && a.Y != nullptr; p.layer[i] = a; };
     set(0, LayerArgs{(const uint16_t*)obs, K0, K0, K0pad, 0, (const uint16_t*)w0, (const uint16_t*)b0, W, nullptr, nullptr, buf[0], W, nullptr, nullptr, 0, M});
     for (int l = 0; l < D; l++)
         set(1 + l, LayerArgs{buf[l & 1], W, W, W, 1, (const uint16_t*)wb + (size_t)l * W * W, (const uint16_t*)bb + (size_t)l * W, W,
@@ -1081,7 +1145,7 @@ extern "C" int bl_mlp_layers_persist_f16(const void* obs, int M, int K0, const v
     hipStream_t hs = (hipStream_t)stream;
     // fresh memory: the counters are zeroed by a launch of their own (a kernel, not a memset node: those replay only once in a captured
     // graph on this ROCm); the kernel leaves them zero, so a caller that keeps the block passes zero_first = 0 from the second call on
-    if (zero_first) hipLaunchKernelGGL(zero_words_kernel, dim3(1), dim3(256), 0, hs, counters, p.rowtiles * p.nlayers + 1);
+    if (zero_first) hipLaunchKernelGGL(zero_words_kernel, dim3(1), dim3(256), 0, hs, counters, local ? p.rowtiles * p.nlayers * 8 + 9 : p.rowtiles * p.nlayers + 1);
 #define BL_PERSIST_LAUNCH(RD, KBC)                                                                                               \
     {                                                                                                                            \
         static size_t raised[64];                                                                                                \
@@ -1096,6 +1160,22 @@ extern "C" int bl_mlp_layers_persist_f16(const void* obs, int M, int K0, const v
     }
 #undef BL_PERSIST_LAUNCH
     return hipGetLastError() == hipSuccess ? BL_OK : BL_ELAUNCH;
+}
+
+extern "C" int bl_mlp_layers_persist_f16(const void* obs, int M, int K0, const void* w0, const void* b0, const void* wb,
+                                         const void* bb, const float* alphas, const void* wh, const void* bh, int W, int D,
+                                         int K0pad, int NH, int NHpad, void* scratch, int* counters, int zero_first, int* error,
+                                         void* policy_out, void* value_out, bl_stream_t stream) {
+    return layers_persist_launch(obs, M, K0, w0, b0, wb, bb, alphas, wh, bh, W, D, K0pad, NH, NHpad, scratch, counters, zero_first, error,
+                                 policy_out, value_out, 0, stream);
+}
+
+extern "C" int bl_mlp_layers_xcd_f16(const void* obs, int M, int K0, const void* w0, const void* b0, const void* wb,
+                                     const void* bb, const float* alphas, const void* wh, const void* bh, int W, int D,
+                                     int K0pad, int NH, int NHpad, void* scratch, int* counters, int zero_first, int* error,
+                                     void* policy_out, void* value_out, bl_stream_t stream) {
+    return layers_persist_launch(obs, M, K0, w0, b0, wb, bb, alphas, wh, bh, W, D, K0pad, NH, NHpad, scratch, counters, zero_first, error,
+                                 policy_out, value_out, 1, stream);
 }
 
 extern "C" int bl_sim_infer_finish(const bl_search_t* s, int sim, const int16_t* leaves, const void* obs, const uint8_t* valid,

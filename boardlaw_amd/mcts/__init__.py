@@ -523,9 +523,15 @@ class MCTSAgent:
     # walked in grid-stride order.  What DOES depend on the size is how far a call advances the generator: 4 x `loops`
     # (torch_rand_geometry).  So a move may be padded from n to cap rows iff every random tensor of the move -- (rows, A) for the
     # Dirichlet and the action draw, (rows, T) for the descents -- has the same `loops` at both sizes.  (Round 4 tested
-    # cap x A <= threads, which switched padding off from 2049 envs at 13x13 and ignored the (rows, T) block: advisor finding.)
+    # cap x A <= threads, which ignored the (rows, T) block: advisor finding.)
+    # One more size-dependent step: the Dirichlet's normalisation.  Up to 127 actions it happens inside bl_sim_plant_root_gamma, row
+    # by row; from 128 on torch's own reduce kernel sums the rows, and it picks its summation order by the tensor's SHAPE -- a
+    # 13x13 move padded from 1051 to 2048 rows differed from the eager move in the last bit of some root logits (found in round 5
+    # by the test below's 13x13 case; round 4 padded there).  Boards from 12x12 up are captured for exactly n rows.
     def _pad_keeps_the_stream(self, n, cap, world):
         A, T = int(np.prod(world.action_space)), int(self.kwargs.get('n_nodes', 64))
+        if A > MoveRng.FUSED_MAX_ACTIONS:
+            return False
         return all(torch_rand_geometry(n * x, world.device)[1] == torch_rand_geometry(cap * x, world.device)[1] for x in (A, T))
 
     def _capacity(self, n, world=None):

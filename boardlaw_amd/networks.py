@@ -348,11 +348,13 @@ class Inference:
             with torch.cuda.device(x0.device):
                 rc = _native.BL_ETOOBIG
                 if self.PERSIST_PLAN:
-                    # all Linears in one launch, workgroups synchronising per row tile (bl_mlp_layers_persist_f16): grids up to 256
+                    # all Linears in one launch, workgroups synchronising per row tile (bl_mlp_layers_persist_f16, or with
+                    # PERSIST_PLAN = 'xcd' bl_mlp_layers_xcd_f16: the hand-off inside one XCD's L2): grids up to 256
                     # workgroups.  The counter block is this call's own (like `scratch`: from the caching allocator, or from a capture's
                     # pool -- two actors sharing this plan on two streams never share one) and is zeroed by the call
-                    counters = torch.empty((-(-M // 32) * (D + 2) + 1,), dtype=torch.int32, device=x0.device)
-                    rc = L.bl_mlp_layers_persist_f16(x0.data_ptr(), M, K0, pk['w0'].data_ptr(), w[1].data_ptr(), pk['wb'].data_ptr(),
+                    local = self.PERSIST_PLAN == 'xcd'
+                    counters = torch.empty((-(-M // 32) * (D + 2) * (8 if local else 1) + 9,), dtype=torch.int32, device=x0.device)
+                    rc = (L.bl_mlp_layers_xcd_f16 if local else L.bl_mlp_layers_persist_f16)(x0.data_ptr(), M, K0, pk['w0'].data_ptr(), w[1].data_ptr(), pk['wb'].data_ptr(),
                                                      pk['bb'].data_ptr(), pk['al'].data_ptr(), pk['wh'].data_ptr(), pk['bh'].data_ptr(),
                                                      W, D, K0pad, NH, NHpad, scratch.data_ptr(), counters.data_ptr(), 1,
                                                      self._persist_error(x0.device).data_ptr(), policy.data_ptr(), value.data_ptr(), st)

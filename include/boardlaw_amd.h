@@ -271,6 +271,18 @@ int bl_mlp_layers_persist_f16(const void* obs /*f16 (M,K0)*/, int M, int K0, con
                               int NH, int NHpad, void* scratch /*f16 (2,M,W)*/, int32_t* counters, int zero_first, int32_t* error,
                               void* policy_out, void* value_out, bl_stream_t stream);
 
+/* The same forward in one launch with the hand-off between two layers kept inside ONE XCD's L2 (round 5): every workgroup reads the
+ * XCD it runs on (HW_REG_XCC_ID), takes a ticket there and works on row tile xcd + 8 * (ticket / column groups) -- the workgroups
+ * of a row tile share an L2 by construction -- so the rows are plain stores, the flags plain words, the loads L1-bypassing; no
+ * device-scope atomic and no write-through store on the path.  Bit-identical to bl_mlp_layers_f16.  Same arguments and limits as
+ * bl_mlp_layers_persist_f16 except: counters = ceil(M/32) * (D + 2) * 8 + 9 words (zero at start, zero again at the end).  Needs
+ * the dispatcher to deal the grid's workgroups evenly over the 8 XCDs (it does: in turn); if an XCD receives too few, the bounded
+ * waits of an unfinished row tile raise `error` (outputs invalid, no hang). */
+int bl_mlp_layers_xcd_f16(const void* obs /*f16 (M,K0)*/, int M, int K0, const void* w0, const void* b0, const void* wb,
+                          const void* bb, const float* alphas, const void* wh, const void* bh, int W, int D, int K0pad,
+                          int NH, int NHpad, void* scratch /*f16 (2,M,W)*/, int32_t* counters, int zero_first, int32_t* error,
+                          void* policy_out, void* value_out, bl_stream_t stream);
+
 /* bl_mlp_forward_f16 followed by bl_sim_finish as ONE launch: the workgroup that took 32 leaves through the network also
  * applies the heads to them, stores logits/v, backs up along the recorded paths and publishes the next q range; what
  * that step reads from the tree is requested at the start of the kernel and arrives under the GEMMs.  Same results as

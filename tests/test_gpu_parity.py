@@ -581,11 +581,14 @@ def test_layers_mlp_matches_autocast_and_the_fused_kernel(S, width, depth, B):
 
 @pytest.mark.parametrize('S,width,depth,B', [(13, 1024, 8, 1024), (13, 1024, 8, 1000), (9, 512, 4, 2048), (9, 512, 4, 77), (13, 768, 3, 200),
                                                  (6, 256, 0, 64), (11, 512, 5, 1500), (7, 256, 2, 4096)])
-def test_persistent_layers_kernel_equals_a_launch_per_linear(S, width, depth, B):
+@pytest.mark.parametrize('mode', [True, 'xcd'])
+def test_persistent_layers_kernel_equals_a_launch_per_linear(S, width, depth, B, mode):
     """bl_mlp_layers_persist_f16 (round 4: all Linears of the forward in ONE launch, workgroups synchronising per row tile through
     release/acquire counters) against bl_mlp_layers_f16 (a launch per Linear): the same arithmetic in the same order, so every output
     bit must be the same -- over repeated calls (the kernel re-zeroes its counters), inside a replayed capture, on ragged row counts,
-    and for grids the kernel refuses (> 256 workgroups: the plan then launches per Linear by itself).  The error word stays clear."""
+    and for grids the kernel refuses (> 256 workgroups: the plan then launches per Linear by itself).  The error word stays clear.
+    mode 'xcd' = bl_mlp_layers_xcd_f16 (round 5): the same launch with the hand-off kept inside one XCD's L2 (workgroups placed by
+    HW_REG_XCC_ID tickets, plain stores, flag words, L1-bypassing loads)."""
     from boardlaw_amd import networks, heads
     torch.manual_seed(S + depth + B)
     net = networks.FCModel(heads.Tensor((S, S, 2)), heads.Masked(S * S), width=width, depth=depth).to(DEV)
@@ -597,7 +600,7 @@ def test_persistent_layers_kernel_equals_a_launch_per_linear(S, width, depth, B)
     plan.refresh()
     plan.FUSED_ALWAYS_BYTES = 0; plan.FUSED_MIN_TILES = 1 << 30          # never the one kernel
     outs = {}
-    for persist in (False, True):
+    for persist in (False, mode):
         plan.PERSIST_PLAN = persist
         res = []
         for rep in range(3):
@@ -605,10 +608,10 @@ def test_persistent_layers_kernel_equals_a_launch_per_linear(S, width, depth, B)
             with torch.no_grad():
                 res.append(plan.raw(w))
         outs[persist] = res
-    for (p0, v0), (p1, v1) in zip(outs[False], outs[True]):
+    for (p0, v0), (p1, v1) in zip(outs[False], outs[mode]):
         assert torch.equal(p0.view(torch.int16), p1.view(torch.int16)) and torch.equal(v0.view(torch.int16), v1.view(torch.int16))
     # a captured forward replays (the counters are zero again after every launch)
-    plan.PERSIST_PLAN = True
+    plan.PERSIST_PLAN = mode
     w = W_(); w.obs = (torch.rand(B, S, S, 2, device=DEV) < .3).half()
     side = torch.cuda.Stream()
     side.wait_stream(torch.cuda.current_stream())
@@ -624,9 +627,54 @@ def test_persistent_layers_kernel_equals_a_launch_per_linear(S, width, depth, B)
         plan.PERSIST_PLAN = False
         with torch.no_grad():
             pe, ve = plan.raw(w)
-        plan.PERSIST_PLAN = True
+        plan.PERSIST_PLAN = mode
         assert torch.equal(pg.view(torch.int16), pe.view(torch.int16)) and torch.equal(vg.view(torch.int16), ve.view(torch.int16)), rep
     assert not plan.persist_error()
+
+
+@pytest.mark.parametrize('mode', [True, 'xcd'])
+def test_persistent_layers_hand_off_under_uneven_load(mode):
+    """The in-launch hand-offs of bl_mlp_layers_persist_f16 / bl_mlp_layers_xcd_f16 while ANOTHER stream keeps part of the chip busy
+    (a loop of GEMMs of changing size: workgroups of a row tile then start at very different times, and the L1s are warm with the
+    previous forward's rows): 40 replays of a captured 1024x8 forward on 1024 rows of 13x13 with fresh inputs, every output word
+    compared with the launch-per-Linear plan; the error word stays clear."""
+    from boardlaw_amd import networks, heads
+    S, width, depth, B = 13, 1024, 8, 1024
+    torch.manual_seed(5)
+    net = networks.FCModel(heads.Tensor((S, S, 2)), heads.Masked(S * S), width=width, depth=depth).to(DEV)
+    with torch.no_grad():
+        for blk in list(net.body)[1:]:
+            getattr(blk, 'α').fill_(float(torch.randn(()) * 0.5))
+    class W_: pass
+    plan = networks.Inference(net, fused=True)
+    plan.refresh()
+    plan.FUSED_ALWAYS_BYTES = 0; plan.FUSED_MIN_TILES = 1 << 30
+    plan.PERSIST_PLAN = mode
+    w = W_(); w.obs = (torch.rand(B, S, S, 2, device=DEV) < .3).half()
+    side, noise = torch.cuda.Stream(), torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        plan.raw(w)
+    torch.cuda.current_stream().wait_stream(side)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=side):
+        pg, vg = plan.raw(w)
+    mats = [torch.randn(n, n, device=DEV, dtype=torch.half) for n in (256, 1024, 3072)]
+    bad = 0
+    for rep in range(40):
+        w.obs.copy_((torch.rand(B, S, S, 2, device=DEV) < .3).half())
+        torch.cuda.synchronize()
+        with torch.cuda.stream(noise):
+            for k in range(6):
+                m_ = mats[(rep + k) % 3]; m_ @ m_
+        g.replay()
+        torch.cuda.synchronize()
+        plan.PERSIST_PLAN = False
+        with torch.no_grad():
+            pe, ve = plan.raw(w)
+        plan.PERSIST_PLAN = mode
+        bad += int((pg.view(torch.int16) != pe.view(torch.int16)).sum()) + int((vg.view(torch.int16) != ve.view(torch.int16)).sum())
+    assert bad == 0 and not plan.persist_error(), bad
 
 
 def test_move_rng_serves_one_block_per_move():

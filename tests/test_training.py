@@ -342,14 +342,15 @@ def test_chunk_evaluator_with_search_agents():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize('S,n,pool,T', [(9, 1000, 2048, 32), (9, 777, 2048, 32), (7, 64, 2048, 32), (9, 2048, 2048, 32), (5, 3, 2048, 32),
-                                        (13, 2100, 4096, 16), (3, 17000, 32768, 100)])
+                                        (13, 2100, 4096, 16), (3, 17000, 32768, 100), (11, 2100, 4096, 16)])
 def test_masked_captured_move_equals_the_eager_masked_call(S, n, pool, T):
     """One move captured for a capacity bucket (2048 / 1024 / 64 rows) serves a call of n envs with the other rows switched off
     on the device (bl_search_t.n_active): decisions identical, bit for bit, to the eager call on exactly those n envs under the
     same seed -- same Dirichlet rows, same uniforms (torch's kernels give row i the same numbers whatever the batch size), and a
     q-range over the n envs only.  Twice in a row: the second replay reuses the capture with another n.
-    (13, 2100): the padded tensors are beyond the size torch's random kernels cover with one element per thread (4096 x 169 > CUs x
-    2048) and the eager ones are not -- the rows' numbers are still the same, so the move is padded (round-4 advisor finding).
+    (13, 2100): from 128 actions on torch's own reduce kernel normalises the Dirichlet draw and picks its summation order by the
+    tensor's shape -- a padded 13x13 move differed from the eager one in the last bit of some root logits (round 4 padded there;
+    found here in round 5) -- so boards from 12x12 up are captured for exactly n rows.
     (3, 17000) with 100 nodes: the (rows, T) block of a 32768-row capture would advance the generator by two Philox rounds where the
     eager call advances it by one -- MCTSAgent._pad_keeps_the_stream refuses the padding and captures for exactly n rows."""
     from boardlaw_amd import networks
@@ -364,9 +365,9 @@ def test_masked_captured_move_equals_the_eager_masked_call(S, n, pool, T):
     net = networks.Inference(networks.FCModel(worlds.obs_space, worlds.action_space, width=256, depth=2).cuda(), fused=True)
     eager = MCTSAgent(net, n_nodes=T, rng=MoveRng())
     graphed = MCTSAgent(net, n_nodes=T, rng=MoveRng(), graph=True)
-    if pool > 2048:
+    if pool > 2048 and S != 11:
         padded = graphed._capacity(n, worlds[:n]) != n
-        assert padded == (S == 13), (S, n, graphed._capacity(n, worlds[:n]))
+        assert not padded, (S, n, graphed._capacity(n, worlds[:n]))
     for m in (n, max(1, n // 2 + 1)):
         sub = worlds[torch.randperm(pool, device='cuda')[:m]]
         for ev in (True, False):
@@ -378,7 +379,7 @@ def test_masked_captured_move_equals_the_eager_masked_call(S, n, pool, T):
                 if x.dtype == torch.half:
                     x, y = x.view(torch.int16), y.view(torch.int16)
                 assert torch.equal(x, y), (k, m, ev)
-    assert len(graphed._graphs) <= 4          # (eval, not eval) x at most two capacity buckets
+    assert len(graphed._graphs) <= 4          # (eval, not eval) x at most two capacity buckets (or two exact sizes)
 
 
 @pytest.mark.gpu

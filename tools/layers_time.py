@@ -25,6 +25,7 @@ res = {}
 plan.FUSED_ALWAYS_BYTES = 1 << 40; res['one kernel'] = timed(lambda: plan.raw(w))
 plan.FUSED_ALWAYS_BYTES = 0; plan.FUSED_MIN_TILES = 1 << 30
 plan.PERSIST_PLAN = True; res['all Linears in one launch (row-tile sync)'] = timed(lambda: plan.raw(w))
+plan.PERSIST_PLAN = 'xcd'; res['all Linears in one launch (hand-off inside the XCD L2)'] = timed(lambda: plan.raw(w))
 plan.PERSIST_PLAN = False; res['launch per Linear'] = timed(lambda: plan.raw(w))
 plan.LAYERS_PLAN = False; res['library GEMMs'] = timed(lambda: plan.raw(w))
 assert not plan.persist_error()
