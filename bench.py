@@ -190,7 +190,9 @@ def hex_kernels(envs=(4096, 1 << 20), steps=1024, boardsize=11):
     out, seats, rewards, terminal) and bl_hex_observe_valid (observe + valid mask).  samples/s as the reference prints them, and
     GB/s of algorithmic bytes against the 8 TB/s peak: step 2 S^2 + 16 B per env (board read + written in place, seat, action,
     rewards), world_step 2 S^2 + 25, observe_valid 10 S^2 + 4 (board + seat read, 8 S^2 of f32 planes + S^2 of mask written).
-    4096 envs is the reference's size -- one 0.5 MB board batch, launch-latency-bound; 2^20 envs is where the kernels meet HBM.
+    4096 envs is the reference's size -- one 0.5 MB board batch, launch-latency-bound; 2^20 envs is where the kernels meet HBM
+    (round 5: 64 consecutive envs per workgroup through LDS with 16-byte loads and stores, the flood as a bit-board fill --
+    bl_hex_*_tiled, profiles/r05_hex_tiles.txt; the dispatchers pick them: step always, observe from 2^17 envs).
     Timed two ways: the reference's way (a host loop of launches, then a synchronise) and as one captured graph of the same
     launches under HIP events (device time only)."""
     from boardlaw_amd import _native

@@ -57,6 +57,9 @@ SYMBOLS = {
     'bl_sim_infer_finish': (_i, [ctypes.POINTER(Search), _i] + [_vp] * 11 + [_i] * 4 + [_vp]),
     'bl_sim_root': (_i, [ctypes.POINTER(Search), _i, _vp, _vp, _vp, _vp]),
     'bl_hex_observe_valid': (_i, [_vp] * 4 + [_i, _i, _vp]),
+    'bl_hex_step_tiled': (_i, [_vp] * 4 + [_i, _i, _vp]),
+    'bl_hex_world_step_tiled': (_i, [_vp] * 3 + [_i] + [_vp] * 4 + [_i, _i, _vp]),
+    'bl_hex_observe_valid_tiled': (_i, [_vp] * 4 + [_i, _i, _vp]),
     'bl_sim_n_leaves': (_i, [ctypes.POINTER(Search), _vp, _vp]),
     'bl_rezero_relu_f32': (_i, [_vp] * 5 + [ctypes.c_long, _vp]),
     'bl_sim_plant_root': (_i, [ctypes.POINTER(Search)] + [_vp] * 5 + [ctypes.c_float, _vp]),

@@ -140,6 +140,19 @@ int bl_hex_observe(const uint8_t* board, const int32_t* seats, float* obs_out, i
 int bl_hex_observe_valid(const uint8_t* board, const int32_t* seats, float* obs_out, uint8_t* valid_out, int B, int boardsize,
                          bl_stream_t stream);
 
+/* The three board kernels as HBM streams (round 5), for boards up to 16x16: a workgroup takes 64 CONSECUTIVE envs -- one contiguous
+ * 16-byte-aligned run of boards -- through LDS with 16-byte loads and stores; four lanes step an env, the flood as a bit-board fill
+ * (the component grows by shifts of a cell bit set instead of sweeps over the board); observe writes its f32 planes as 16-byte and
+ * its mask as 4-byte stores.  Same results as the functions above, which call these whenever the boards qualify (step, world_step) resp.
+ * from 2^17 envs on (observe: below that a group of lanes per env fills more of the chip and a launch is shorter).  BL_EINVAL if board / obs / valid pointers are not
+ * 16-byte aligned, BL_ETOOBIG beyond 16x16; bl_hex_observe_valid_tiled: valid_out may be null. */
+int bl_hex_step_tiled(uint8_t* board, const int32_t* seats, const int32_t* actions, float* rewards_out, int B, int boardsize, bl_stream_t stream);
+int bl_hex_world_step_tiled(const uint8_t* board_in, const int32_t* seats_in, const void* actions, int actions_i64,
+                            uint8_t* board_out, int32_t* seats_out, float* rewards_out, uint8_t* terminal_out, int B, int S,
+                            bl_stream_t stream);
+int bl_hex_observe_valid_tiled(const uint8_t* board, const int32_t* seats, float* obs_out, uint8_t* valid_out, int B, int boardsize,
+                               bl_stream_t stream);
+
 /* ================= fused search step for Hex (no reference counterpart) ==================
  * One simulation of boardlaw/mcts/__init__.py:108-140 is  descend -> expand -> world.step -> observe -> network ->
  * store -> backup.  The reference runs ~25 torch ops and 4 host syncs around its three kernels; here everything

@@ -85,6 +85,62 @@ def test_hex_random_games_vs_oracle(oracle, S, B):
         board, seats, _, _ = oracle.hex_world_step(board, seats, actions)
 
 
+@pytest.mark.parametrize('S,B', [(1, 5), (2, 70), (3, 1000), (5, 64), (9, 4096), (11, 4097), (13, 333), (16, 129)])
+def test_hex_tiled_kernels_vs_oracle(oracle, S, B):
+    """The board kernels as HBM streams (bl_hex_step_tiled / bl_hex_world_step_tiled / bl_hex_observe_valid_tiled, round 5: 64
+    consecutive envs per workgroup through LDS, the flood as a bit-board fill, 16-byte loads and stores) against the C oracle along
+    random games to the end, both seats, ragged batch sizes (the last workgroup's run of boards is not a multiple of 16 bytes),
+    1x1 to 16x16 -- called directly, whatever sizes the dispatchers send to them; plus their refusals."""
+    from boardlaw_amd import _native
+    L = _native.lib()
+    rng = np.random.default_rng(S + B)
+    board = np.zeros((B, S, S), np.uint8); seats = np.zeros(B, np.int32)
+    st = _native.stream(torch.device(DEV))
+    for step in range(min(3 * S * S, 260)):
+        obs = oracle.hex_observe(board, seats)
+        valid = (obs == 0).all(-1).reshape(B, -1)
+        actions = (rng.random(valid.shape) * valid).argmax(-1).astype(np.int32)
+        tb, ts, ta = torch.from_numpy(board).to(DEV), torch.from_numpy(seats).to(DEV), torch.from_numpy(actions).to(DEV)
+        o = torch.full((B, S, S, 2), 7., device=DEV); vm = torch.full((B, S * S), 7, dtype=torch.uint8, device=DEV)
+        assert L.bl_hex_observe_valid_tiled(tb.data_ptr(), ts.data_ptr(), o.data_ptr(), vm.data_ptr(), B, S, st) == 0
+        assert np.array_equal(to_np(o), obs) and np.array_equal(to_np(vm).astype(bool), valid), step
+        o2 = torch.full((B, S, S, 2), 7., device=DEV)
+        assert L.bl_hex_observe_valid_tiled(tb.data_ptr(), ts.data_ptr(), o2.data_ptr(), None, B, S, st) == 0 and torch.equal(o, o2)
+        raw = board.copy(); want = oracle.hex_step(raw, seats, actions)
+        nb, ns, nr, nt = oracle.hex_world_step(board, seats, actions)
+        ob, os_ = torch.full_like(tb, 9), torch.full_like(ts, 9)
+        r2 = torch.full((B, 2), 9., device=DEV); term = torch.full((B,), 9, dtype=torch.uint8, device=DEV)
+        a64 = ta.long()
+        assert L.bl_hex_world_step_tiled(tb.data_ptr(), ts.data_ptr(), (a64 if step % 2 else ta).data_ptr(), step % 2, ob.data_ptr(), os_.data_ptr(),
+                                         r2.data_ptr(), term.data_ptr(), B, S, st) == 0
+        assert np.array_equal(to_np(ob), nb) and np.array_equal(to_np(os_), ns) and np.array_equal(to_np(r2), nr) and np.array_equal(to_np(term).astype(bool), nt), step
+        r = torch.full((B, 2), 9., device=DEV)
+        assert L.bl_hex_step_tiled(tb.data_ptr(), ts.data_ptr(), ta.data_ptr(), r.data_ptr(), B, S, st) == 0
+        assert np.array_equal(to_np(tb), raw) and np.array_equal(to_np(r), want), step
+        board, seats = nb, ns
+    big = torch.zeros((4, 17, 17), dtype=torch.uint8, device=DEV); z = torch.zeros(4 * 17 * 17 * 2, dtype=torch.int32, device=DEV)
+    assert L.bl_hex_step_tiled(big.data_ptr(), z.data_ptr(), z.data_ptr(), z.data_ptr(), 4, 17, st) == _native.BL_ETOOBIG
+    assert L.bl_hex_observe_valid_tiled(big.data_ptr(), z.data_ptr(), z.data_ptr(), None, 4, 17, st) == _native.BL_ETOOBIG
+    odd = torch.zeros(4 * 81 + 16, dtype=torch.uint8, device=DEV)[1:]
+    assert L.bl_hex_step_tiled(odd.data_ptr(), z.data_ptr(), z.data_ptr(), z.data_ptr(), 4, 9, st) == _native.BL_EINVAL
+
+
+def test_hex_observe_tiled_through_the_dispatcher():
+    """bl_hex_observe_valid / bl_hex_observe send batches of 2^17 envs and more to the tiled kernel: the same planes and mask as the
+    lanes-per-env kernel computes for the same boards in two halves."""
+    from boardlaw_amd.hex import cuda as hcuda, Hex
+    torch.manual_seed(1)
+    B, S = (1 << 17) + 77, 7
+    w = Hex.initial(B, S, device=DEV)
+    for _ in range(12):
+        w, _ = w.step((torch.rand(w.valid.shape, device=DEV) * w.valid).argmax(-1), check=False)
+    obs = hcuda.observe(w.board, w.seats)
+    h = B // 2
+    assert torch.equal(obs[:h], hcuda.observe(w.board[:h].contiguous(), w.seats[:h].contiguous()))
+    assert torch.equal(obs[h:], hcuda.observe(w.board[h:].clone(), w.seats[h:].clone()))
+    assert torch.equal(w.valid, (obs == 0).all(-1).reshape(B, S * S))
+
+
 def test_hex_reference_known_answers():
     """boardlaw/hex/tests.py:58-91 and hex/__init__.py:274-297 through the product's Hex world."""
     from boardlaw_amd.hex import Hex, cuda as hcuda
