@@ -168,15 +168,16 @@ __device__ __forceinline__ float readlane_f(float v, int lane) {
 // orders it (ATen/native/cuda/Reduce.cuh: setReduceConfig / thread_reduce_impl / block_x_reduce): block width
 // Wr = min(largest power of two <= A, 64); lane x < Wr adds v[x] and v[x + Wr] (when that exists) into two of its four
 // accumulators, combines them ((a0 + a1) + 0) + 0, and the lanes are then summed by shfl_down with offsets 1, 2, 4, ... Wr/2 --
-// the balanced tree ((v0+v1)+(v2+v3))+... that an XOR butterfly with the same offsets gives EVERY lane (float addition
-// commutes bit for bit).  `own` = this lane's v[x] (0 for x >= Wr), `second` = v[x + Wr] or 0.  Lets a kernel that holds a row
+// the balanced tree ((v0+v1)+(v2+v3))+... that an XOR butterfly with the same offsets gives lanes 0 .. Wr-1 (float addition
+// commutes bit for bit); lane 0's total is then handed to every lane (for Wr < 64 the lanes from Wr up only summed zeros: round 5's
+// first version returned those, and every board below 8x8 drew action 0 -- found by the seeded-agent test at 5x5).  `own` = this lane's v[x] (0 for x >= Wr), `second` = v[x + Wr] or 0.  Lets a kernel that holds a row
 // in registers reproduce `t.sum(-1)` bit for bit without the launch (A >= 128 takes torch's vectorised path, whose order depends
 // on each row's address alignment: callers keep torch's own kernels there).
 // ------------------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ float torch_row_sum(float own, float second, int Wr) {
     float v = (own + second) + 0.f + 0.f;
     for (int off = 1; off < Wr; off <<= 1) v = v + __shfl_xor(v, off, BL_WAVE);
-    return v;
+    return __shfl(v, 0, BL_WAVE);
 }
 __host__ __device__ __forceinline__ int last_pow2_le(int a) { int w = 1; while (2 * w <= a) w *= 2; return w; }
 

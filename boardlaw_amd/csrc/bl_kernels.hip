@@ -1179,7 +1179,7 @@ __global__ void __launch_bounds__(BL_WAVE) sim_plant_root_kernel(Search s, const
         if (gamma_Wr) {
             // the Dirichlet sample from its gamma variates, over ALL actions (iters <= 2 here): lane x < Wr sums elements x and x + Wr
             float own, second;
-            if (W == 64) { own = d[0]; second = d[1]; }                                  // A >= 64: Wr == W, the lane's own two elements
+            if (gamma_Wr == 64) { own = d[0]; second = d[1]; }                           // A >= 64: Wr == W == 64, the lane's own two elements
             else if (gamma_Wr == W) { own = d[0]; second = 0.f; }                        // A a power of two: one element per lane
             else { const float up = __shfl(d[0], (lane + gamma_Wr) & 63, BL_WAVE); own = lane < gamma_Wr ? d[0] : 0.f; second = (lane < gamma_Wr && lane + gamma_Wr < A) ? up : 0.f; }
             const float gsum = torch_row_sum(own, second, gamma_Wr);
