@@ -782,18 +782,23 @@ __global__ void __launch_bounds__(256) hex_observe_tile_kernel(const uint8_t* bo
     for (int q = tid; q < quads; q += 256) {
         float o[8];
         uint32_t vm = 0;
+        // the quad's first cell by division (idx < 64 * 1024: exact in f32), the other three by stepping (cell, row, column) with wrap-around
+        int idx = 4 * q;
+        int e = (int)(((float)idx + 0.5f) * invA), a = idx - e * A;
+        int i = (int)(((float)a + 0.5f) * invS), j = a - i * S;
+        bool flip = flips[e] != 0;
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            const int idx = 4 * q + k;
             o[2 * k] = 0.f; o[2 * k + 1] = 0.f;
             if (idx < bytes) {
-                const int e = (int)(((float)idx + 0.5f) * invA), a = idx - e * A;       // idx < 64 * 1024: exact in f32
-                const int i = (int)(((float)a + 0.5f) * invS), j = a - i * S;
-                const bool flip = flips[e] != 0;
-                const int color = color_of(all[e * A + (flip ? j * S + i : a)]);
+                const int c = all[e * A + (flip ? j * S + i : a)];
+                const int color = c < 7 ? (0x1412 >> (2 * c)) & 3 : 2;  // color_of as a table: codes 1,3,4 -> 0; 2,5,6 -> 1; anything else -> 2
                 if (color < 2) { if ((flip ? 1 - color : color) == 0) o[2 * k] = 1.f; else o[2 * k + 1] = 1.f; }
                 else vm |= 1u << (8 * k);
             }
+            idx++; a++; j++;
+            if (j == S) { j = 0; i++; }
+            if (a == A) { a = 0; i = 0; j = 0; e++; flip = (e < nE) && flips[e] != 0; }
         }
         if (4 * q + 3 < bytes) {
             ((float4*)obase)[2 * q] = make_float4(o[0], o[1], o[2], o[3]);
