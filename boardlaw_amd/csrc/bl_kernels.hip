@@ -661,12 +661,19 @@ __device__ __forceinline__ int hex_step_quad(uint8_t* cells, int S, int seat, in
         uint32_t P[NW], M[NW];
 #pragma unroll
         for (int w = 0; w < NW; w++) {
+            // branch-free: all eight reads of a word in flight at once (a read beyond the board -- at most 31 bytes, into the next
+            // env's cells or the pad behind the last one -- is masked out by `a < A`); as `if (...) bits |= ...` the compiler put every
+            // cell behind its own EXEC branch with a wait per read: ten instructions and an LDS round trip per cell
             uint32_t bits = 0;
+            uint8_t c[8];
+#pragma unroll
+            for (int i = 0; i < 8; i++) c[i] = cells[32 * w + 4 * i + gl];
 #pragma unroll
             for (int i = 0; i < 8; i++) {
                 const int a = 32 * w + 4 * i + gl;
-                if (flooding && a < A && cells[a] == (uint8_t)plain) bits |= 1u << (4 * i + gl);
+                bits |= (uint32_t)((c[i] == (uint8_t)plain) & (a < A)) << (4 * i + gl);
             }
+            if (!flooding) bits = 0;
             bits |= (uint32_t)dpp_i<0xB1, 0xf>(0, (int)bits);            // quad_perm [1,0,3,2]
             bits |= (uint32_t)dpp_i<0x4E, 0xf>(0, (int)bits);            // quad_perm [2,3,0,1]
             P[w] = bits;
@@ -682,34 +689,38 @@ __device__ __forceinline__ int hex_step_quad(uint8_t* cells, int S, int seat, in
             for (int w = 0; w < NW; w++) y[w] = __builtin_amdgcn_alignbit(w + 1 < NW ? x[w + 1] : 0u, x[w], k);
         };
         for (int it = 0; it < A; it++) {
-            uint32_t X[NW], Y[NW], t[NW], Ex[NW];
+            // neighbours of the set M: L = (M with a right neighbour) << 1, R = (M with a left neighbour) >> 1, and the rows above and
+            // below as ONE shift each -- cell a - S and a - S + 1 are (M | L) >> S, cell a + S and a + S - 1 are (M | R) << S
+            uint32_t L[NW], R[NW], U[NW], D[NW], t[NW];
 #pragma unroll
-            for (int w = 0; w < NW; w++) { X[w] = M[w] & hm.not_last[w]; Y[w] = M[w] & hm.not_first[w]; }
-            shl(M, S, Ex);
-            shr(M, S, t);
+            for (int w = 0; w < NW; w++) { U[w] = M[w] & hm.not_last[w]; D[w] = M[w] & hm.not_first[w]; }
+            shl(U, 1, L);
+            shr(D, 1, R);
 #pragma unroll
-            for (int w = 0; w < NW; w++) Ex[w] |= t[w];
-            shl(X, 1, t);
-#pragma unroll
-            for (int w = 0; w < NW; w++) Ex[w] |= t[w];
-            shr(Y, 1, t);
-#pragma unroll
-            for (int w = 0; w < NW; w++) Ex[w] |= t[w];
-            shr(X, S - 1, t);
-#pragma unroll
-            for (int w = 0; w < NW; w++) Ex[w] |= t[w];
-            shl(Y, S - 1, t);
+            for (int w = 0; w < NW; w++) { U[w] = M[w] | L[w]; D[w] = M[w] | R[w]; }
+            shr(U, S, t);
+            shl(D, S, U);
             uint32_t grew = 0;
 #pragma unroll
-            for (int w = 0; w < NW; w++) { const uint32_t nw = (Ex[w] | t[w]) & P[w] & ~M[w]; M[w] |= nw; grew |= nw; }
+            for (int w = 0; w < NW; w++) { const uint32_t nw = (L[w] | R[w] | t[w] | U[w]) & P[w] & ~M[w]; M[w] |= nw; grew |= nw; }
             if (!__any(grew != 0)) break;
         }
 #pragma unroll
         for (int w = 0; w < NW; w++) {
+            if (32 * (w + 1) <= A) {
+                // a word that lies inside the board: every lane rewrites its eight cells, select(label, old value) -- two instructions a
+                // cell and no EXEC juggling (a lane's cells are its own: nobody else writes them; envs that do not flood have M = 0)
+                uint8_t c[8];
 #pragma unroll
-            for (int i = 0; i < 8; i++) {
-                const int a = 32 * w + 4 * i + gl;
-                if (flooding && a < A && ((M[w] >> (4 * i + gl)) & 1u)) cells[a] = (uint8_t)label;
+                for (int i = 0; i < 8; i++) c[i] = cells[32 * w + 4 * i + gl];
+#pragma unroll
+                for (int i = 0; i < 8; i++) cells[32 * w + 4 * i + gl] = ((M[w] >> (4 * i + gl)) & 1u) ? (uint8_t)label : c[i];
+            } else if (32 * w < A) {
+#pragma unroll
+                for (int i = 0; i < 8; i++) {
+                    const int a = 32 * w + 4 * i + gl;
+                    if (a < A && ((M[w] >> (4 * i + gl)) & 1u)) cells[a] = (uint8_t)label;
+                }
             }
         }
     }
@@ -1656,7 +1667,7 @@ static void hex_tile_launch(const uint8_t* board_in, uint8_t* board_out, const i
         if (a % S < S - 1) hm.not_last[a >> 5] |= 1u << (a & 31);
     }
     const dim3 grid((unsigned)((B + 63) / 64));
-    const size_t lds = (size_t)((64 * A + 15) & ~15);
+    const size_t lds = (size_t)((64 * A + 15) & ~15) + 32;      // + the scan's over-read behind the last env
     if (A <= 128)
         hipLaunchKernelGGL((hex_step_tile_kernel<4>), grid, dim3(256), lds, stream, board_in, board_out, seats_in, actions, actions_i64, seats_out,
                            rewards, terminal, B, S, world, hm);
