@@ -85,7 +85,7 @@ def test_hex_random_games_vs_oracle(oracle, S, B):
         board, seats, _, _ = oracle.hex_world_step(board, seats, actions)
 
 
-@pytest.mark.parametrize('S,B', [(1, 5), (2, 70), (3, 1000), (5, 64), (9, 4096), (11, 4097), (13, 333), (16, 129)])
+@pytest.mark.parametrize('S,B', [(1, 5), (2, 70), (3, 1000), (5, 64), (9, 4096), (11, 4097), (12, 100), (13, 333), (15, 77), (16, 129)])
 def test_hex_tiled_kernels_vs_oracle(oracle, S, B):
     """The board kernels as HBM streams (bl_hex_step_tiled / bl_hex_world_step_tiled / bl_hex_observe_valid_tiled, round 5: 64
     consecutive envs per workgroup through LDS, the flood as a bit-board fill, 16-byte loads and stores) against the C oracle along
