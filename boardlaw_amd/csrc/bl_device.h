@@ -248,6 +248,76 @@ __device__ __forceinline__ int hex_step_group(uint8_t* cells, int S, int seat, i
     return win;
 }
 
+// Hex's step by ONE WAVE on a board in LDS, the flood as a bit-board fill in wave-uniform registers (round 5; the board tiles of
+// bl_kernels.hip do the same with four lanes per env).  hex_step_group's sweeps cost an LDS round trip per cell and neighbour behind an
+// EXEC branch each, and two or more sweeps with a barrier whenever the new stone touches an edge group -- 4 k cycles and up at the END of
+// every descent's dependent chain.  Here: the six neighbours of the new stone are read by six lanes at once; the mover's plain-coloured
+// cells become a bit set by one ballot per 64 cells; the component grows from the stone by 64-bit shifts on uniform values (scalar
+// ALU) until it stops; its cells get the label.  Same component, same bytes (cuda.cu:18-74: the net effect is order-independent).
+// NW64 = ceil(A / 64) words; all 64 lanes active; the caller has made the staged board visible to the wave.
+template <int NW64>
+__device__ __forceinline__ int hex_step_wave(uint8_t* cells, int S, int seat, int action, int lane) {
+    const int A = S * S;
+    const float invS = 1.0f / (float)S;
+    const int qd = (int)(((float)action + 0.5f) * invS), rm = action - qd * S;
+    const int row = seat == 0 ? qd : rm, col = seat == 0 ? rm : qd;       // white plays transposed, cuda.cu:88-91
+    const int start = row * S + col;
+    int code = EMPTY;
+    if (lane < 6) {
+        const int r = row + (lane < 2 ? -1 : (lane < 4 ? 0 : 1));
+        const int c = col + (lane == 1 || lane == 3 ? 1 : (lane == 2 || lane == 4 ? -1 : 0));     // (-1,0) (-1,+1) (0,-1) (0,+1) (+1,-1) (+1,0)
+        if (r < 0) code = TOP; else if (r >= S) code = BOT; else if (c < 0) code = LEFT; else if (c >= S) code = RIGHT;
+        else code = cells[r * S + c];
+    }
+    const bool aT = __builtin_amdgcn_ballot_w64(code == TOP) != 0, aB = __builtin_amdgcn_ballot_w64(code == BOT) != 0;
+    const bool aL = __builtin_amdgcn_ballot_w64(code == LEFT) != 0, aR = __builtin_amdgcn_ballot_w64(code == RIGHT) != 0;
+    int label, win = 0, plain;
+    if (seat) { if (aL && aR) win = -1; label = aL ? LEFT : (aR ? RIGHT : WHITE); plain = WHITE; }
+    else      { if (aT && aB) win = +1; label = aT ? TOP : (aB ? BOT : BLACK); plain = BLACK; }
+    if (label < TOP) {
+        if (lane == 0) cells[start] = (uint8_t)plain;                     // no flood: the plain colour (cuda.cu:134)
+    } else {
+        unsigned long long P[NW64], M[NW64], NF[NW64], NL[NW64];
+#pragma unroll
+        for (int w = 0; w < NW64; w++) {
+            const int a = 64 * w + lane;
+            const int r = (int)(((float)a + 0.5f) * invS), c = a - r * S;
+            const bool in = a < A;
+            P[w] = __builtin_amdgcn_ballot_w64(in && cells[in ? a : 0] == (uint8_t)plain);
+            NF[w] = __builtin_amdgcn_ballot_w64(in && c > 0);
+            NL[w] = __builtin_amdgcn_ballot_w64(in && c < S - 1);
+            M[w] = (start >> 6) == w ? 1ull << (start & 63) : 0ull;
+        }
+        auto shl = [&](const unsigned long long (&x)[NW64], int k, unsigned long long (&y)[NW64]) {      // 1 <= k <= 63
+#pragma unroll
+            for (int w = 0; w < NW64; w++) y[w] = (x[w] << k) | (w ? x[w - 1] >> (64 - k) : 0ull);
+        };
+        auto shr = [&](const unsigned long long (&x)[NW64], int k, unsigned long long (&y)[NW64]) {
+#pragma unroll
+            for (int w = 0; w < NW64; w++) y[w] = (x[w] >> k) | (w + 1 < NW64 ? x[w + 1] << (64 - k) : 0ull);
+        };
+        for (int it = 0; it < A; it++) {
+            unsigned long long L[NW64], R[NW64], U[NW64], D[NW64], t[NW64];
+#pragma unroll
+            for (int w = 0; w < NW64; w++) { U[w] = M[w] & NL[w]; D[w] = M[w] & NF[w]; }
+            shl(U, 1, L);
+            shr(D, 1, R);
+#pragma unroll
+            for (int w = 0; w < NW64; w++) { U[w] = M[w] | L[w]; D[w] = M[w] | R[w]; }
+            shr(U, S, t);
+            shl(D, S, U);
+            unsigned long long grew = 0;
+#pragma unroll
+            for (int w = 0; w < NW64; w++) { const unsigned long long nw = (L[w] | R[w] | t[w] | U[w]) & P[w] & ~M[w]; M[w] |= nw; grew |= nw; }
+            if (grew == 0) break;
+        }
+#pragma unroll
+        for (int w = 0; w < NW64; w++) if ((M[w] >> lane) & 1ull) cells[64 * w + lane] = (uint8_t)label;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); __builtin_amdgcn_wave_barrier();
+    return win;
+}
+
 __device__ __forceinline__ int color_of(int c) { return (c == BLACK || c == TOP || c == BOT) ? 0 : ((c == WHITE || c == LEFT || c == RIGHT) ? 1 : 2); }
 
 struct Search {

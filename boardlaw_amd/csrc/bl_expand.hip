@@ -428,7 +428,7 @@ __global__ void __launch_bounds__(BL_WAVE * NW, (RMAX <= 3 ? 8 : 4)) sim_expand2
     const uint8_t* src = s.boards + (envbase + parent) * A;
     for (int a = lane; a < A; a += 64) cells[a] = src[a];
     __syncthreads();
-    const int win = hex_step_group<64>(cells, S, seat, action, true, lane);
+    const int win = hex_step_wave<(RMAX + 1) / 2>(cells, S, __builtin_amdgcn_readfirstlane(seat), __builtin_amdgcn_readfirstlane(action), lane);     // one wave is left: the flood as a bit-board fill
     // Hex.step tail, hex/__init__.py:183-190
     const bool term = win != 0;
     const int new_seat = term ? 0 : 1 - seat;
