@@ -514,16 +514,21 @@ __global__ void __launch_bounds__(WAVES * 64) mlp_kernel(Params p, FinArgs f) {
         long envbase[EPW]; int leaf[EPW];
         float ev[EPW][2], mx[EPW], sum[EPW];
         // policy head: lane l < Wsm holds actions l + it * Wsm; A <= 128 here, so that is register `it` of the valid bytes
+        // the heads' outputs of the four envs: all twelve LDS reads in flight at once, selected afterwards (as `cond ? h2f(Out[..]) : -inf`
+        // under `if (lane < A)` every read sat behind its own EXEC branch with a wait: eight LDS round trips in a row; a read past a
+        // row's NH entries -- lane + Wsm up to 127 -- stays inside Out + the scratch behind it and is discarded)
+        uint16_t o0[EPW], o1[EPW], ov[EPW];
 #pragma unroll
         for (int e = 0; e < EPW; e++) {
             const int r = EPW * wave + e;
+            o0[e] = Out[r * p.NHpad + lane]; o1[e] = Out[r * p.NHpad + lane + Wsm]; ov[e] = Out[r * p.NHpad + p.NH - 1];
+        }
+#pragma unroll
+        for (int e = 0; e < EPW; e++) {
             envbase[e] = (long)(fb[e] < 0 ? 0 : fb[e]) * T;
             leaf[e] = __builtin_amdgcn_readfirstlane(fleaf[e]);
-            ev[e][0] = -INFINITY; ev[e][1] = -INFINITY;
-            if (lane < Wsm) {
-                if (lane < A) ev[e][0] = ((fvbits >> (2 * e)) & 1u) ? h2f(Out[r * p.NHpad + lane]) : -INFINITY;
-                if (two && lane + Wsm < A) ev[e][1] = ((fvbits >> (2 * e + 1)) & 1u) ? h2f(Out[r * p.NHpad + lane + Wsm]) : -INFINITY;
-            }
+            const bool k0 = lane < Wsm && lane < A && ((fvbits >> (2 * e)) & 1u), k1 = lane < Wsm && two && lane + Wsm < A && ((fvbits >> (2 * e + 1)) & 1u);
+            ev[e][0] = k0 ? h2f(o0[e]) : -INFINITY; ev[e][1] = k1 ? h2f(o1[e]) : -INFINITY;
             mx[e] = two ? ((ev[e][0] > ev[e][1]) ? ev[e][0] : ev[e][1]) : ev[e][0];
         }
         CLK(54)
@@ -566,7 +571,7 @@ __global__ void __launch_bounds__(WAVES * 64) mlp_kernel(Params p, FinArgs f) {
                 if (two && lane + Wsm < A) dst[lane + Wsm] = lb[e][1];
             }
             // value head
-            const uint16_t tv = f2h(tanhf(h2f(Out[r * p.NHpad + p.NH - 1])));
+            const uint16_t tv = f2h(tanhf(h2f(ov[e])));
             const int mover = __builtin_amdgcn_readfirstlane(fmover[e]);
             vb0[e] = (mover == 0) ? tv : (uint16_t)(tv ^ 0x8000u); vb1[e] = (uint16_t)(vb0[e] ^ 0x8000u);
             if (fb[e] >= 0 && lane == 0) { f.v[(envbase[e] + leaf[e]) * 2] = vb0[e]; f.v[(envbase[e] + leaf[e]) * 2 + 1] = vb1[e]; }
