@@ -158,6 +158,13 @@ __device__ __forceinline__ void load_qrange(const uint32_t* qr, float& lo, float
     a = wave_max_u32(a); b = wave_max_u32(b);       // DPP reductions + readlane (the shuffle butterflies were 12 LDS round trips)
     lo = dec(~a); hi = dec(b);
 }
+// The same in two halves, so that a kernel can ISSUE the slot loads together with its other prologue loads and reduce later (as one
+// call behind other loads' uses the compiler issues it after their waits: a second memory round trip at the start of every workgroup).
+__device__ __forceinline__ uint2 qrange_words(const uint32_t* qr) { return *(const uint2*)(qr + BL_QSTRIDE * (threadIdx.x & 63)); }
+__device__ __forceinline__ void qrange_reduce(uint2 v, float& lo, float& hi) {
+    const uint32_t a = wave_max_u32(v.x ^ BL_QBIAS), b = wave_max_u32(v.y ^ BL_QBIAS);
+    lo = dec(~a); hi = dec(b);
+}
 
 __device__ __forceinline__ float readlane_f(float v, int lane) {
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));

@@ -142,6 +142,10 @@ __global__ void __launch_bounds__(BL_WAVE * NW, (RMAX <= 3 ? 8 : 4)) sim_expand2
     int info[KT];         // nk | seat << 16 | terminal << 17
     int rd[KT];           // rand[b,t] (f16 bits)
     int fav[KT];          // most visited child of slot t, or -1
+    // every load of the prologue goes out before anything waits: the q-range slots and c_puct first (they depend on nothing), then the
+    // node slots -- ONE memory round trip instead of three in a row at the start of every workgroup
+    const uint2 qwords = qrange_words(s.qrange + (long)BL_QWORDS * sim);
+    const uint16_t cpuct_bits = s.c_puct[b];
 #pragma unroll
     for (int kt = 0; kt < KT; kt++) {
         const int tt = kt * 64 + lane;
@@ -155,9 +159,9 @@ __global__ void __launch_bounds__(BL_WAVE * NW, (RMAX <= 3 ? 8 : 4)) sim_expand2
         }
     }
     float lo, hi;
-    load_qrange(s.qrange + (long)BL_QWORDS * sim, lo, hi);
+    qrange_reduce(qwords, lo, hi);
     const float rden = hi - lo + 1.e-4f;
-    const float cpuct = h2f(s.c_puct[b]);
+    const float cpuct = h2f(cpuct_bits);
     // transition_q (cuda.cu:101-105) of every node slot, both seats, once per launch: lane t normalises its own slot's
     // w/(n + 1e-4); a level then fetches a child's q with one bpermute instead of dividing twice per level
     uint32_t qp[KT];      // q[b,t,0] | q[b,t,1] << 16  (f16 bits)
