@@ -1095,6 +1095,155 @@ __global__ void __launch_bounds__(BL_WAVE) sim_finish_kernel(Search s, int sim, 
     }
 }
 
+// The same step with its memory round trips counted (round 5).  sim_finish_kernel above chases its data: leaves[b]; valid, then the
+// policy entry behind a branch on it, per iteration; the exp-table gather per iteration; path[0], then path[1 + j], then that node's
+// fields; after the stores a barrier and every slot's (w, n) again for the q range; a checking load before each atomic -- about ten
+// dependent trips of ~1 us for a wave that has nothing else to do (13.5 us per launch at config 4's shape, 17.4 in the torch-GEMM
+// and fp32 plans of config 2).  Here everything that depends on nothing but b goes out at once (leaf, value, mover, path length, the
+// path, every slot's (w, n), valid and policy rows), the second trip fetches what depends on the path (terminal, rewards) and the
+// exp-table entries, the path nodes' (w, n) come out of the slot registers through LDS, and the q range reuses the slot registers
+// with the path's nodes replaced -- no barrier + reload.  Same arithmetic in the same order, same stores.  T <= 64 KT, A <= W ITERS.
+template <typename RAW, int KT, int ITERS>
+__global__ void __launch_bounds__(BL_WAVE) sim_finish_fast_kernel(Search s, int sim, const int16_t* leaves, const RAW* policy_raw,
+                                                                 const RAW* value_raw, const uint8_t* valid,
+                                                                 const int32_t* leaf_seats, int W) {
+    __shared__ uint32_t lw[64 * KT];
+    __shared__ int16_t ln[64 * KT];
+    const int S = s.S, A = S * S, T = s.T;
+    const int b = blockIdx.x, lane = threadIdx.x;
+    if (b >= active_envs(s)) return;
+    const long envbase = (long)b * T;
+    // ---- trip 1: everything that depends on b alone
+    const int leaf = leaves[b];
+    const RAW vraw = value_raw[b];
+    const int mover = leaf_seats[b];
+    const int16_t* path = s.path + (long)b * (T + 2);
+    const int len = path[0];
+    int pj[KT];
+    uint32_t sw[KT]; int sn[KT];
+#pragma unroll
+    for (int c = 0; c < KT; c++) {
+        const int t = 64 * c + lane;
+        pj[c] = 0; sw[c] = 0; sn[c] = 0;
+        if (t < T) { pj[c] = path[1 + t]; sw[c] = *(const uint32_t*)(s.w + (envbase + t) * 2); sn[c] = s.n[envbase + t]; }
+    }
+    float pe[ITERS]; uint8_t vd[ITERS]; bool in[ITERS];
+#pragma unroll
+    for (int it = 0; it < ITERS; it++) {
+        const int a = lane + it * W;
+        in[it] = lane < W && a < A;
+        pe[it] = 0.f; vd[it] = 0;
+        if (in[it]) { vd[it] = valid[(long)b * A + a]; pe[it] = raw2f(policy_raw[(long)b * A + a]); }
+    }
+    // ---- policy head (sim_finish_kernel's arithmetic, operation for operation)
+    uint16_t lb[ITERS];
+    {
+        float e[ITERS];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int it = 0; it < ITERS; it++) {
+            e[it] = (in[it] && vd[it]) ? pe[it] : -INFINITY;
+            mx = (it == 0) ? e[0] : ((mx > e[it]) ? mx : e[it]);
+        }
+        for (int off = W / 2; off > 0; off /= 2) { const float o = __shfl_xor(mx, off, W); mx = (mx < o) ? o : mx; }
+        float sum = 0.f;
+#pragma unroll
+        for (int it = 0; it < ITERS; it++) sum += expf(e[it] - mx);
+        for (int off = W / 2; off > 0; off /= 2) sum = sum + __shfl_xor(sum, off, W);
+        const float lsum = logf(sum);
+#pragma unroll
+        for (int it = 0; it < ITERS; it++) lb[it] = in[it] ? f2h(e[it] - mx - lsum) : (uint16_t)0;
+    }
+    // ---- trip 2: the exp-table entries of the row, and what depends on the path (terminal, rewards); the slots' (w, n) go into LDS
+    float pi[ITERS];
+#pragma unroll
+    for (int it = 0; it < ITERS; it++) pi[it] = (s.cpi && in[it]) ? s.exp_table[lb[it]] : 0.f;
+    int term[KT]; uint32_t rr[KT];
+#pragma unroll
+    for (int c = 0; c < KT; c++) {
+        const int t = 64 * c + lane;
+        term[c] = 0; rr[c] = 0;
+        if (t < len) { const long i = envbase + pj[c]; term[c] = s.terminal[i]; rr[c] = *(const uint32_t*)(s.rewards + i * 2); }
+        if (t < T) { lw[t] = sw[c]; ln[t] = (int16_t)sn[c]; }
+    }
+    {   // stores of the policy row
+        uint16_t* dst = s.logits + (envbase + leaf) * A;
+#pragma unroll
+        for (int it = 0; it < ITERS; it++) if (in[it]) dst[lane + it * W] = lb[it];
+    }
+    // ---- value head
+    const uint16_t tv = f2h(tanhf(raw2f(vraw)));
+    const uint16_t vb0 = (mover == 0) ? tv : (uint16_t)(tv ^ 0x8000u), vb1 = (uint16_t)(vb0 ^ 0x8000u);
+    if (lane == 0) { s.v[(envbase + leaf) * 2] = vb0; s.v[(envbase + leaf) * 2 + 1] = vb1; }
+    __syncthreads();
+    // ---- backup (cuda.cu:205-236), leaf -> root; node j's old (w, n) from the slot values
+    float v0 = h2f(vb0), v1 = h2f(vb1);
+#pragma unroll
+    for (int c = KT - 1; c >= 0; c--) {
+        const int base = 64 * c;
+        if (base < len) {                                       // wave-uniform
+            const int j = base + lane;
+            const bool onp = j < len;
+            const uint32_t wold = onp ? lw[pj[c]] : 0u;
+            const int nold = onp ? (int)ln[pj[c]] : 0;
+            float w0 = h2f((uint16_t)wold), w1 = h2f((uint16_t)(wold >> 16));
+            const float r0 = h2f((uint16_t)rr[c]), r1 = h2f((uint16_t)(rr[c] >> 16));
+            const int top_j = min(len - 1 - base, BL_WAVE - 1);
+            for (int l = top_j; l >= 0; l--) {
+                if (__builtin_amdgcn_readlane(term[c], l)) { v0 = 0.f; v1 = 0.f; }
+                v0 += readlane_f(r0, l); v1 += readlane_f(r1, l);
+                if (lane == l) { w0 = h2f(f2h(w0 + h2f(f2h(v0)))); w1 = h2f(f2h(w1 + h2f(f2h(v1)))); }
+            }
+            if (onp) {
+                const long i = envbase + pj[c];
+                const uint32_t wnew = (uint32_t)f2h(w0) | ((uint32_t)f2h(w1) << 16);
+                const int16_t nnew = (int16_t)(nold + 2);        // n += 1 once per seat (cuda.cu:230)
+                *(uint32_t*)(s.w + i * 2) = wnew; s.n[i] = nnew;
+                lw[pj[c]] = wnew; ln[pj[c]] = nnew;
+            }
+        }
+    }
+    // ---- the compacted row (compact_store's order: iterations ascending, lanes ascending)
+    if (s.cpi) {
+        int count = 0;
+        const long node = envbase + leaf;
+#pragma unroll
+        for (int it = 0; it < ITERS; it++) {
+            const bool keep = in[it] && pi[it] != 0.f;
+            const unsigned long long mk = __ballot(keep);
+            if (keep) {
+                const int jj = count + __builtin_popcountll(mk & ((1ull << lane) - 1ull));
+                s.cpi[node * A + jj] = pi[it];
+                s.cca[node * A + jj] = 0xffff0000u | (uint32_t)(lane + it * W);
+            }
+            count += __builtin_popcountll(mk);
+        }
+        if (lane == 0) s.nk[node] = (int16_t)count;
+    }
+    __syncthreads();
+    // ---- transition_q's range over the env's slots, the path's nodes with their new statistics
+    uint32_t nmin = 0, vmax = 0;
+#pragma unroll
+    for (int c = 0; c < KT; c++) {
+        const int t = 64 * c + lane;
+        if (t < T) {
+            const uint32_t wv = lw[t];
+            const float den = (float)ln[t] + 1.e-4f;
+            const float qa_[2] = {h2f((uint16_t)wv), h2f((uint16_t)(wv >> 16))}, qb_[2] = {den, den};
+            float qq_[2];
+            ieee_div_n<2>(qa_, qb_, qq_);
+            const uint32_t e0 = enc(qq_[0]), e1 = enc(qq_[1]);
+            nmin = max(nmin, max(~e0, ~e1)); vmax = max(vmax, max(e0, e1));
+        }
+    }
+    nmin = wave_max_u32(nmin); vmax = wave_max_u32(vmax);
+    if (lane == 0) {
+        uint32_t* p = s.qrange + (long)BL_QWORDS * (sim + 1) + BL_QSTRIDE * (blockIdx.x % BL_QSLOTS);
+        q_atomic_max_checked(p, nmin);
+        q_atomic_max_checked(p + 1, vmax);
+    }
+}
+
 // Compacted rows (bl_device.h: compact_store) for logits somebody else stored: node leaves[b] of every env, or node 0
 // when leaves is null (a planted root).  One wave per env.
 __global__ void __launch_bounds__(BL_WAVE) compact_rows_kernel(Search s, const int16_t* leaves) {
@@ -1859,6 +2008,20 @@ static int sim_finish_impl(int f32, const bl_search_t* s, int sim, const int16_t
     int np2 = 1; while (np2 < A) np2 *= 2;
     const int W = np2 < 64 ? np2 : 64, iters = np2 / W;
     if (iters > 16) return BL_ETOOBIG;
+    if (s->T <= 256 && iters <= 4) {
+        // the common shapes: the version with its loads batched (sim_finish_fast_kernel)
+        const int KT = (s->T + 63) / 64;
+        hipStream_t hs = (hipStream_t)stream;
+        const Search ss = to_search(s);
+#define FIN(R_, K_, I_) hipLaunchKernelGGL((sim_finish_fast_kernel<R_, K_, I_>), dim3(s->B), dim3(64), 0, hs, ss, sim, leaves, (const R_*)policy_raw, (const R_*)value_raw, valid, leaf_seats, W)
+#define FIN_I(R_, K_) { if (iters == 1) FIN(R_, K_, 1); else if (iters == 2) FIN(R_, K_, 2); else FIN(R_, K_, 4); }
+#define FIN_K(R_) { if (KT == 1) FIN_I(R_, 1) else if (KT == 2) FIN_I(R_, 2) else FIN_I(R_, 4) }
+        if (f32) FIN_K(float) else FIN_K(uint16_t)
+#undef FIN_K
+#undef FIN_I
+#undef FIN
+        return check_launch();
+    }
     if (f32)
         hipLaunchKernelGGL(sim_finish_kernel<float>, dim3(s->B), dim3(64), 0, (hipStream_t)stream, to_search(s), sim, leaves,
                            (const float*)policy_raw, (const float*)value_raw, valid, leaf_seats, W, iters);
