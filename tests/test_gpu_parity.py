@@ -295,10 +295,12 @@ def premixed(oracle, B, S, moves, seed):
 
 
 @pytest.mark.parametrize('S,B,T', [(9, 4096, 64), (5, 64, 16), (13, 1024, 48), (3, 16384, 8), (11, 333, 32), (13, 96, 256), (2, 5, 3), (9, 1, 64), (19, 24, 40), (32, 3, 12),
-                                   (4, 2048, 64), (6, 2048, 64), (7, 2048, 64), (8, 2048, 64), (10, 2048, 64)])     # config 5's sizes between 3 and 11 at its batch size
+                                   (4, 2048, 64), (6, 2048, 64), (7, 2048, 64), (8, 2048, 64), (10, 2048, 64),     # config 5's sizes between 3 and 11 at its batch size
+                                   (9, 32768, 64)])        # the reference's own operating point: main.run's n_envs = 32*1024 (boardlaw/main.py:147)
 def test_full_size_search_vs_oracle(oracle, S, B, T):
-    """BASELINE config 2 at its full size (9x9, 4096 envs, 64 nodes) and neighbours: a whole search on the GPU against
-    the oracle-driven search on the host, with a device-independent integer network.  Everything must be identical."""
+    """BASELINE config 2 at its full size (9x9, 4096 envs, 64 nodes) and neighbours, and the reference's default actor shape
+    (9x9, 32768 envs, 64 nodes): a whole search on the GPU against the oracle-driven search on the host, with a
+    device-independent integer network.  Everything must be identical."""
     from boardlaw_amd.hex import Hex
     from boardlaw_amd.mcts import MCTS
     board, seats = premixed(oracle, B, S, (S * S) // 3, seed=S * 1000 + T + SEED)
@@ -1138,7 +1140,8 @@ def assert_search_equals(m, want):
 @pytest.mark.parametrize('S,B,T,width,depth,mode', [(9, 4096, 64, 512, 4, 'eager'), (9, 4096, 64, 512, 4, 'graph'),
                                                     (13, 1024, 256, 1024, 8, 'eager'), (5, 64, 16, 256, 2, 'graph'),
                                                     (9, 333, 64, 512, 4, 'eager-torch-gemms'),
-                                                    (13, 1024, 256, 1024, 8, 'graph-plan'), (9, 512, 64, 1024, 4, 'eager-plan')])
+                                                    (13, 1024, 256, 1024, 8, 'graph-plan'), (9, 512, 64, 1024, 4, 'eager-plan'),
+                                                    (9, 32768, 64, 512, 4, 'graph')])     # `bench.py --envs 32768`: boardlaw/main.py:147's n_envs
 def test_bench_launch_sequence_vs_oracle(oracle, S, B, T, width, depth, mode):
     """What bench.py times -- bl_sim_plant_root, then T-1 x (bl_sim_expand -> bl_sim_infer_finish) with the real network's
     fused fp16 plan (13x13/256 nodes: bl_mlp_forward_f16 + bl_sim_finish, the T > 64 route; '-plan': what the plan picks for

@@ -36,6 +36,19 @@ class World:
         self.obs, self.valid, self.seats = obs, valid, seats
 
 
+def plan_decisions(inf, world):
+    """(logits, v) in f16 as MCTS.simulate stores them under the inference plan `inf`: the plan's pre-head outputs (`inf.raw`: the
+    library GEMMs with fused=False, bl_mlp_forward_f16 / bl_mlp_layers_f16 with fused=True) through the heads in torch's own ops
+    under autocast -- which bl_sim_finish reproduces bit for bit (tests/test_gpu_parity.py::test_finish_heads_match_torch).
+    NOT `inf(world)`: calling the plan object runs the wrapped module unchanged (fp32)."""
+    from boardlaw_amd import heads
+    with torch.no_grad(), torch.autocast('cuda'):
+        p, v = inf.raw(world)
+        assert p.dtype == torch.half and v.dtype == torch.half
+        logits = torch.nn.functional.log_softmax(p.masked_fill(~world.valid, -np.inf), -1).half()
+        return logits, heads.scatter_values(torch.tanh(v), world.seats).half()
+
+
 @pytest.mark.parametrize('name', SEARCHES)
 def test_fcmodel_reproduces_reference_outputs(oracle, name):
     """networks.py:37-40, heads.py:47-52,101-104,128-142 in f32 on the CPU: identical bits."""
@@ -137,9 +150,13 @@ def test_plant_root_kernel_against_reference_root(name):
 def test_gpu_network_against_reference_outputs(name):
     """The reference network's parameters on the GPU against the outputs the reference recorded (f32 on its CPU path):
       * the module in fp32: |dlogit| <= 1e-4 (different GEMM summation order, device expf/logf), v within 1e-5;
-      * the fp16 inference plans (torch GEMMs; the fused MFMA kernel where the width allows) + bl_sim_finish's heads,
-        i.e. what MCTS.simulate stores: within 3 f16 ulp of the reference's stored f16 values on >= 99 % of the finite
-        logits and never more than 2^-6 relative -- fp16 autocast vs f32 is the reference's own GPU/CPU gap."""
+      * the module under fp16 autocast, i.e. what the reference's MCTS.simulate stores on a GPU: within 3 f16 ulp of the f16
+        values the reference stored (f32 on its CPU path, then `.half()`) on >= 99 % of the finite logits, none beyond 16 ulp
+        -- fp16 autocast vs f32 is the reference's own GPU/CPU gap;
+      * the torch-GEMM inference plan (networks.Inference(fused=False)): bit-identical to the module under autocast;
+      * the fused plan (networks.Inference(fused=True)) where it applies: these fixtures' networks are 8..32 wide, below the
+        MFMA kernels' 128, so the plan must fall back to the torch GEMMs and stay bit-identical.  The MFMA kernel itself is held
+        against the reference's 512-wide recording in tests/test_reference_fixtures.py::test_fused_mfma_network_against_reference_outputs."""
     from boardlaw_amd import networks
     from boardlaw_amd.hex import Hex
     g = gold(name)
@@ -164,6 +181,11 @@ def test_gpu_network_against_reference_outputs(name):
         assert np.array_equal(got16 != 0xfc00, fin16)
         d16 = ulp16(got16[fin16], want16[fin16])
         assert (d16 <= 3).mean() >= 0.99 and d16.max() <= 16, (d16.max(), (d16 <= 3).mean())
+        for fused in (False, True):
+            inf = networks.Inference(net, fused=fused)
+            assert inf.fused_params(world.n_envs) is None, 'a network this narrow must stay on the torch GEMMs'
+            pl, pv = plan_decisions(inf, world)
+            assert np.array_equal(f16bits(pl), got16) and np.array_equal(f16bits(pv), f16bits(h.v)), (name, i, fused)
 
 
 @pytest.mark.gpu

@@ -359,13 +359,13 @@ def test_fused_mfma_network_against_reference_outputs():
     reference's own 512x4 parameters against the f16 values the reference stored for its leaf evaluations (f32 on its CPU path,
     then `.half()`, mcts/__init__.py:131-136).  Tolerance (fp16 autocast vs f32 -- the reference's own GPU/CPU gap): >= 99 % of
     the finite logits within 3 f16 ulp, none beyond 16; -inf pattern identical; v within 4 f16 ulp on >= 99 %, none beyond 2^-7 abs."""
-    from test_network_golden import reference_network, f16bits
+    from test_network_golden import reference_network, f16bits, plan_decisions
     from boardlaw_amd import networks
     from boardlaw_amd.hex import Hex
     g = _gold('search_9x9_w512.npz')
     S, B, T, width, depth, n_moves, seed = (int(x) for x in g['meta'])
     inf = networks.Inference(reference_network(g, 'cuda'), fused=True)
-    assert inf.fused_params(B) is not None, 'the fused plan must be the one under test'
+    assert inf.fused_params(B) is not None and inf.prefers_fused(B), 'the fused plan must be the one under test'
     created = g['m0_parents'][:, 1:] != -1                       # (B, T-1): simulation s created node s
     checked = 0
     for sim in range(1, T):
@@ -374,10 +374,9 @@ def test_fused_mfma_network_against_reference_outputs():
             continue
         world = Hex(board=torch.from_numpy(np.ascontiguousarray(g['m0_boards'][:, sim])).cuda(),
                     seats=torch.from_numpy(np.ascontiguousarray(g['m0_seats'][:, sim])).cuda().int())
-        with torch.no_grad():
-            d = inf(world)
+        logits, v = plan_decisions(inf, world)        # inf.raw -> bl_mlp_forward_f16 (round 5 called inf(world): the fp32 module)
         want_l, want_v = g['m0_tree_logits'][rows, sim], g['m0_tree_v'][rows, sim]
-        got_l, got_v = f16bits(d.logits)[rows], f16bits(d.v)[rows]
+        got_l, got_v = f16bits(logits)[rows], f16bits(v)[rows]
         fin = want_l != 0xfc00
         assert np.array_equal(got_l != 0xfc00, fin), sim
         dl = _ulp16(got_l[fin], want_l[fin])
