@@ -18,7 +18,7 @@ _vp, _i = ctypes.c_void_p, ctypes.c_int
 
 class Tune(ctypes.Structure):
     """bl_tune_t: explicit tuning choices (zero = defaults); results never depend on them."""
-    _fields_ = [(k, _i) for k in ('fold_fast', 'expand_waves', 'expand_deep', 'expand_legacy', 'group', 'mlp_no_xcd', 'lazy_init', 'expand_envs', 'expand_help', 'powf_libm')]
+    _fields_ = [(k, _i) for k in ('fold_fast', 'expand_waves', 'expand_deep', 'expand_legacy', 'group', 'mlp_no_xcd', 'lazy_init', 'expand_envs', 'mlp_rows', 'powf_libm')]
 
 
 class Search(ctypes.Structure):
@@ -129,7 +129,7 @@ def tune(device=None):
     parity tests of the kernel variants); the library itself reads no environment."""
     return Tune(fold_fast=fold_fast(device) if device is not None else 0, expand_waves=_env_int('BL_EXPAND_WAVES'),
                 expand_deep=_env_int('BL_EXPAND_DEEP'), expand_legacy=_env_int('BL_EXPAND_LEGACY'), group=_env_int('BL_FORCE_GROUP'),
-                mlp_no_xcd=int(os.environ.get('BL_MLP_XCD', '1') == '0'), powf_libm=_env_int('BL_POWF_LIBM'))
+                mlp_no_xcd=int(os.environ.get('BL_MLP_XCD', '1') == '0'), mlp_rows=_env_int('BL_MLP_ROWS'), powf_libm=_env_int('BL_POWF_LIBM'))
 
 
 GENLIBPATH = os.path.join(HERE, 'libbl_torchgen.so')

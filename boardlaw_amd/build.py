@@ -27,6 +27,8 @@ GEN_STAMP = GEN_LIB + '.torch'      # the torch version the shim was compiled ag
 # -ffp-contract=off: the search kernels must round like the reference's CPU path (no FMA); see DESIGN.md.
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-ffp-contract=off', '-fPIC', '-fno-gpu-flush-denormals-to-zero',
          '-I' + os.path.join(ROOT, 'include')]
+# measurement builds only (tools/ab_build.sh: variants of a kernel's compile-time switches, e.g. BL_HIPCC_EXTRA=-DBLM_RD64=2)
+FLAGS += os.environ.get('BL_HIPCC_EXTRA', '').split()
 
 
 def _newer(target, deps):

@@ -1929,11 +1929,15 @@ static int sim_expand_impl(const bl_search_t* s, int sim, const void* rands, int
         // template set (A > 384 or T > 256) fall through to the general kernel
         // waves per env: two fill the chip's 8192 wave slots at 4096 envs; up to 1024 envs four fit twice over and a batch then
         // covers four guessed levels (13x13, 1024 envs x 256 sims: 44.2 -> 40.3 ms per move; 9x9 at 2048 envs: no gain, at 4096 a loss)
-        const int waves = tune.expand_waves ? tune.expand_waves : (s->B <= 1024 ? 4 : 2);
+        // From 16384 envs on the launch is several times the chip's wave slots and what binds is VALU issue, not one env's chain: the
+        // helper wave's guessed evaluations (5.6 evaluated nodes for 4.8 needed) then cost more than they hide -- one wave per env
+        // (9x9 x 64 sims, us per launch with 2 / 1 waves: 8192 envs 77.7 / 78.2, 16384 125.0 / 113.3, 32768 221.4 / 185.6;
+        // profiles/r06_envs_sweep_waves.txt).  Results do not depend on the choice.
+        const int waves = tune.expand_waves ? tune.expand_waves : (s->B <= 1024 ? 4 : s->B < 16384 ? 2 : 1);
         // (expand_envs > 1 was round 4's shared-workgroup kernel: removed, BL_EINVAL)
         const int envs = tune.expand_envs ? tune.expand_envs : 1;
         rc = bl_expand2_launch(to_search(s), sim, rands, leaves, obs, valid, leaf_seats, counters, tune.fold_fast != 0,
-                               waves, tune.expand_deep, tune.expand_waves ? 1 : envs, tune.expand_help, (hipStream_t)stream);
+                               waves, tune.expand_deep, tune.expand_waves ? 1 : envs, 0, (hipStream_t)stream);
         if (rc != BL_ETOOBIG) return rc;
     }
     const int G = pick_group(s->B, A, tune.group), K = pick_k(A, G);

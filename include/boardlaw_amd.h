@@ -40,7 +40,7 @@ typedef void* bl_stream_t; /* hipStream_t */
 typedef struct {
     int fold_fast;     /* 1: bl_sim_expand pads its dependent DPP fold steps with ONE wait state instead of the ISA's two (30 % faster).
                           Set it only for a device on which bl_selftest() returned 0; 0: the ISA-padded fold */
-    int expand_waves;  /* waves per env in bl_sim_expand: 0 = default (4 up to 1024 envs, else 2); 1, 2, 4, or 21 = two nodes per wave */
+    int expand_waves;  /* waves per env in bl_sim_expand: 0 = default (4 up to 1024 envs, 2 below 16384, else 1); 1, 2, 4, or 21 = two nodes per wave */
     int expand_deep;   /* speculative guesses only from this descent level on (default 0) */
     int expand_legacy; /* 1: bl_sim_expand runs the general kernel on logits/children instead of the compacted rows */
     int group;         /* lanes per env in the general kernels: 0 = heuristic (64), or 8 / 16 / 32 / 64 */
@@ -53,7 +53,8 @@ typedef struct {
     int expand_envs;   /* reserved (ABI 3 layout kept): round 4's shared-workgroup bl_sim_expand -- 2 / 4 envs per workgroup, the waves
                           of finished descents helping the ones still going; bit-exact, slower at every batch size -- was removed in
                           round 5.  0 or 1; anything else makes bl_sim_expand return BL_EINVAL */
-    int expand_help;   /* reserved (was: the shared-workgroup kernel's help threshold); ignored */
+    int mlp_rows;      /* rows per workgroup in bl_sim_infer_finish: 0 = by the batch (32; 64 once 32-row tiles outnumber the CUs and
+                          the width allows), or 32 / 64.  (This slot was round 4's reserved `expand_help`: ABI 4 layout kept.) */
     int powf_libm;     /* NOT a tuning choice but a second parity target: 1 = the Newton derivative term divides by glibc's
                           powf(bot, 2) (what the reference's own JIT build computes: no -O flag, boardlaw/cuda.py:29-45,
                           boardlaw/mcts/cpp/cpu.cpp:60) instead of bot * bot (what g++ -O1 and up make of it; the default).  The two

@@ -576,7 +576,8 @@ def test_sharded_search_with_merged_qrange_equals_unsharded(oracle):
         assert same == merge
 
 
-@pytest.mark.parametrize('S,width,depth,B', [(9, 512, 4, 4096), (7, 128, 4, 1000), (8, 256, 4, 33), (6, 128, 1, 64), (13, 512, 2, 300), (3, 128, 4, 5000), (13, 1024, 8, 1024), (11, 768, 3, 200), (19, 1024, 2, 70), (9, 512, 5, 100)])
+@pytest.mark.parametrize('S,width,depth,B', [(9, 512, 4, 4096), (7, 128, 4, 1000), (8, 256, 4, 33), (6, 128, 1, 64), (13, 512, 2, 300), (3, 128, 4, 5000), (13, 1024, 8, 1024), (11, 768, 3, 200), (19, 1024, 2, 70), (9, 512, 5, 100),
+                                              (9, 512, 4, 8300), (5, 256, 2, 9000)])      # more 32-row tiles than CUs: the 64-row instantiations
 def test_fused_mlp_matches_autocast(S, width, depth, B):
     """bl_mlp_forward_f16 (one MFMA kernel for all Linears) vs the module under fp16 autocast: same rounding points,
     different GEMM summation order => a tolerance test.  Tolerance: 3 f16 ulps of the largest activation scale plus
@@ -603,6 +604,14 @@ def test_fused_mlp_matches_autocast(S, width, depth, B):
     # and the overwhelming majority of outputs should be bit-identical or 1 ulp off
     close = ((p0.float() - p1.float()).abs() <= 2**-9 * p0.float().abs().clamp(min=2**-5)).float().mean()
     assert close > 0.99, float(close)
+    if B > 8192:
+        # a row's outputs do not depend on the batch it is in: the first rows as a batch of their own (32-row tiles) against
+        # the same rows inside the big batch (64-row tiles), bit for bit
+        class W2_: pass
+        w2 = W2_(); w2.obs = w.obs[:1000].contiguous()
+        with torch.no_grad(), torch.autocast('cuda'):
+            p2, v2 = fused.raw(w2)
+        assert torch.equal(p2, p1[:1000]) and torch.equal(v2, v1[:1000])
 
 
 @pytest.mark.parametrize('S,width,depth,B', [(13, 1024, 8, 1024), (9, 512, 4, 1000), (7, 128, 4, 33), (13, 768, 3, 200), (19, 1024, 2, 70), (6, 256, 0, 64), (11, 512, 5, 2049)])
@@ -990,6 +999,63 @@ def test_infer_finish_in_one_launch_equals_two_launches(S, B, T, width, depth):
         assert torch.equal(_native.qrange_decode(a._qrange[row]), _native.qrange_decode(b._qrange[row]))
     assert np.array_equal(bits16(a.root_probs()), bits16(b.root_probs()))
     assert (to_np(a.stats.n)[:, 0] == 2 * (T - 1)).all()
+
+
+@pytest.mark.parametrize('S,B,T,width,depth', [(9, 1000, 64, 512, 4), (9, 8193, 24, 512, 4), (5, 100, 16, 256, 2), (11, 33, 64, 512, 1), (3, 70, 8, 256, 3),
+                                                 (7, 513, 20, 512, 0)])
+def test_infer_finish_on_64_row_tiles_equals_32_row_tiles(S, B, T, width, depth):
+    """bl_sim_infer_finish with 64 rows per workgroup (bl_tune_t.mlp_rows = 64; what the library picks by itself once the 32-row
+    tiles outnumber the CUs: every weight fragment then feeds two MFMAs, and a wave finishes eight envs in two passes) against
+    the 32-row kernel: the k order of every accumulator is the same, so every array of the finished search must be identical --
+    ragged batches (rows beyond M in both row groups), one tile, many tiles; the (9, 8193) case is also the library's own choice."""
+    from boardlaw_amd import hex, networks, _native
+    from boardlaw_amd.mcts import MCTS
+    torch.manual_seed(S * 100 + T)
+    worlds = hex.Hex.initial(B, S, device=DEV)
+    for _ in range((S * S) // 3):
+        r = torch.rand(worlds.valid.shape, device=DEV) * worlds.valid
+        worlds, _ = worlds.step(r.argmax(-1), check=False)
+    net = networks.FCModel(worlds.obs_space, worlds.action_space, width=width, depth=depth).to(DEV)
+    with torch.no_grad():
+        for p_ in net.parameters():
+            if p_.ndim == 0:
+                p_.fill_(0.3)
+    inf = networks.Inference(net, fused=True)
+    assert inf.fused_params(B) is not None
+    out = []
+    for rows in (32, 64, 0):
+        m = MCTS(worlds, n_nodes=T, obs_half=True)
+        m._search.tune.mlp_rows = rows
+        torch.manual_seed(5)
+        m.initialize(inf)
+        torch.manual_seed(6)                 # same uniforms for all runs
+        for _ in range(T - 1):
+            m.simulate(inf)
+        out.append(m)
+    a = out[0]
+    for b in out[1:]:
+        for name in ('tree.children', 'tree.parents', 'tree.relation', 'stats.n', 'stats.w', 'decisions.logits', 'decisions.v', 'worlds.board', '_nk'):
+            x, y = a, b
+            for part in name.split('.'):
+                x, y = getattr(x, part), getattr(y, part)
+            assert np.array_equal(to_np(x), to_np(y)), (name, b._search.tune.mlp_rows)
+        # the compacted rows' kept entries (what lies beyond a row's nk entries is never written)
+        kept = (torch.arange(a._cpi.shape[-1], device=DEV)[None, None] < a._nk[..., None]) & (a.tree.parents != -1)[..., None]
+        kept[:, 0] = torch.arange(a._cpi.shape[-1], device=DEV)[None] < a._nk[:, 0, None]
+        assert torch.equal(a._cpi[kept].view(torch.int32), b._cpi[kept].view(torch.int32)) and torch.equal(a._cca[kept], b._cca[kept])
+        for row in range(1, T + 1):
+            assert torch.equal(_native.qrange_decode(a._qrange[row]), _native.qrange_decode(b._qrange[row]))
+        assert np.array_equal(bits16(a.root_probs()), bits16(b.root_probs()))
+    assert (to_np(a.stats.n)[:, 0] == 2 * (T - 1)).all()
+    # widths whose two 64-row activation buffers do not fit the LDS refuse the explicit request
+    if width == 512 and S == 9 and B == 1000:
+        wide = networks.Inference(networks.FCModel(worlds.obs_space, worlds.action_space, width=1024, depth=1).to(DEV), fused=True)
+        wide.FUSED_MIN_TILES = 0
+        m = MCTS(worlds, n_nodes=4, obs_half=True)
+        m._search.tune.mlp_rows = 64
+        m.initialize(wide)
+        with pytest.raises(_native.NativeError):
+            m.simulate(wide)
 
 
 @pytest.mark.parametrize('S,B', [(9, 4096), (3, 50), (13, 257), (32, 9), (1, 4)])
