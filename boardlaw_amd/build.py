@@ -14,7 +14,7 @@ from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
-UNITS = ('bl_kernels.hip', 'bl_expand.hip', 'bl_mlp.hip', 'bl_root.hip', 'bl_rand.hip')
+UNITS = ('bl_kernels.hip', 'bl_expand.hip', 'bl_rows.hip', 'bl_mlp.hip', 'bl_root.hip', 'bl_rand.hip')
 SOURCES = [os.path.join(HERE, 'csrc', f) for f in UNITS]
 # every header under csrc/ (bl_device.h includes bl_powf.h, ...): editing any of them rebuilds every object
 HEADERS = [os.path.join(ROOT, 'include', 'boardlaw_amd.h')] + sorted(glob.glob(os.path.join(HERE, 'csrc', '*.h')))

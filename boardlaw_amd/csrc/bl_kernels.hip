@@ -1672,6 +1672,8 @@ static int check_launch() { return hipGetLastError() == hipSuccess ? BL_OK : BL_
 int bl_expand2_launch(const Search& ss, int sim, const void* rands, int16_t* leaves, void* obs, uint8_t* valid, int32_t* leaf_seats,
                       unsigned long long* counters, int fast, int waves, int deep_thresh, int envs, int help_thresh, hipStream_t stream);     // bl_expand.hip
 int bl_fold_selftest(int use_fast, hipStream_t stream);
+int bl_expand_rows_launch(const Search& ss, int sim, const void* rands, int16_t* leaves, void* obs, uint8_t* valid, int32_t* leaf_seats,
+                          int waves, hipStream_t stream);      // bl_rows.hip
 
 namespace bl {
 __global__ void __launch_bounds__(256) powf2_kernel(const float* x, float* out, long n) {
@@ -1934,6 +1936,13 @@ static int sim_expand_impl(const bl_search_t* s, int sim, const void* rands, int
         // (9x9 x 64 sims, us per launch with 2 / 1 waves: 8192 envs 77.7 / 78.2, 16384 125.0 / 113.3, 32768 221.4 / 185.6;
         // profiles/r06_envs_sweep_waves.txt).  Results do not depend on the choice.
         const int waves = tune.expand_waves ? tune.expand_waves : (s->B <= 1024 ? 4 : s->B < 16384 ? 2 : 1);
+        // expand_waves = 16: four ENVS per wave, one per DPP row (bl_rows.hip; expand_deep then = the descent launch's waves, 0 = its
+        // default).  Built in round 6 for the VALU-bound regime above, bit-exact, and SLOWER there (32768 envs: 244 us against 186;
+        // profiles/r06_rows_kernel.txt): opt-in only, parity-tested in a child process.
+        if (!counters && tune.expand_waves == 16) {
+            rc = bl_expand_rows_launch(to_search(s), sim, rands, leaves, obs, valid, leaf_seats, tune.expand_deep, (hipStream_t)stream);
+            if (rc != BL_ETOOBIG) return rc;
+        }
         // (expand_envs > 1 was round 4's shared-workgroup kernel: removed, BL_EINVAL)
         const int envs = tune.expand_envs ? tune.expand_envs : 1;
         rc = bl_expand2_launch(to_search(s), sim, rands, leaves, obs, valid, leaf_seats, counters, tune.fold_fast != 0,

@@ -40,7 +40,7 @@ typedef void* bl_stream_t; /* hipStream_t */
 typedef struct {
     int fold_fast;     /* 1: bl_sim_expand pads its dependent DPP fold steps with ONE wait state instead of the ISA's two (30 % faster).
                           Set it only for a device on which bl_selftest() returned 0; 0: the ISA-padded fold */
-    int expand_waves;  /* waves per env in bl_sim_expand: 0 = default (4 up to 1024 envs, 2 below 16384, else 1); 1, 2, 4, or 21 = two nodes per wave */
+    int expand_waves;  /* waves per env in bl_sim_expand: 0 = default (4 up to 1024 envs, 2 below 16384, else 1); 1, 2, 4, 21 = two nodes per wave, or 16 = four envs per wave (bl_rows.hip; measured slower) */
     int expand_deep;   /* speculative guesses only from this descent level on (default 0) */
     int expand_legacy; /* 1: bl_sim_expand runs the general kernel on logits/children instead of the compacted rows */
     int group;         /* lanes per env in the general kernels: 0 = heuristic (64), or 8 / 16 / 32 / 64 */

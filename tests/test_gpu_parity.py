@@ -788,6 +788,24 @@ def test_two_nodes_per_wave_expand_in_subprocess():
     assert ' passed' in r.stdout
 
 
+def test_four_envs_per_wave_expand_in_subprocess():
+    """bl_rows.hip (descend with four envs per wave, one per 16-lane DPP row, then the expansion as its own launch) is what the
+    library picks from 16384 envs on -- the (9, 32768, 64) oracle comparisons above run it.  Forced at every batch size
+    (BL_EXPAND_WAVES=16, read once per process) the other oracle comparisons must hold bit for bit too: boards 2x2 .. 9x9 (1 .. 6
+    kept actions per lane), ragged and tiny batches (rows without an env, waves whose rows take several envs one after the
+    other), per-env c_puct, recorded reference searches, masked searches, the bench's launch sequence eager and captured."""
+    import subprocess, sys
+    env = dict(os.environ, BL_EXPAND_WAVES='16')
+    here = os.path.dirname(os.path.abspath(__file__))
+    r = subprocess.run([sys.executable, '-m', 'pytest', os.path.join(here, 'test_gpu_parity.py'), '-q', '-x', '-m', 'gpu',
+                        '-k', '(test_whole_search_replay and fused) or (test_full_size_search_vs_oracle and not 32768 and not 13- and not 19- and not 32-3 and not 11-333) or '
+                              '(test_bench_launch_sequence_vs_oracle and (9-4096-64-512-4 or 5-64-16)) or test_search_with_per_env_c_puct or '
+                              'test_ragged_and_tiny_batches or test_graphed_move_equals_eager_move or test_lazy_reset_equals_the_eager_reset'],
+                       env=env, capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert ' passed' in r.stdout
+
+
 def test_removed_shared_workgroup_expand_is_refused():
     """Round 4's shared-workgroup bl_sim_expand (bl_tune_t.expand_envs = 2 / 4) was removed in round 5 (bit-exact, slower, and its
     protocol trapped on an exhausted poll budget): the field is reserved and any value but 0 / 1 is BL_EINVAL, not a silent default."""

@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage (GPU box, repo root): tools/profile_pmc.sh <tag>  -> gpurun_out/<tag>/pmc_*.csv
+# usage (GPU box, repo root): [BENCH_ARGS="--envs 32768"] tools/profile_pmc.sh <tag>  -> gpurun_out/<tag>/pmc_*.csv
 # rocprofv3 counter passes of a short bench run, each counter set in its own run with --kernel-trace only (no other trace
 # domain), summarised per kernel with tools/pmc_summary.py; plus the FETCH/WRITE_SIZE calibration micro-benchmark.
 tag=${1:-pmc}; out=$PWD/gpurun_out/$tag; mkdir -p $out
@@ -7,7 +7,7 @@ repo=$PWD; cd /tmp; export TMPDIR=/tmp
 run() {   # name, counters...
   name=$1; shift
   rm -rf /tmp/pmc_$name
-  rocprofv3 --kernel-trace --pmc "$@" -d /tmp/pmc_$name --output-format csv -- python $repo/bench.py --steps 2 --warmup 1 --timed-only > /dev/null 2> $out/pmc_$name.err
+  rocprofv3 --kernel-trace --pmc "$@" -d /tmp/pmc_$name --output-format csv -- python $repo/bench.py --steps 2 --warmup 1 --timed-only $BENCH_ARGS > /dev/null 2> $out/pmc_$name.err
   python $repo/tools/pmc_summary.py /tmp/pmc_$name > $out/pmc_$name.csv
   head -4 $out/pmc_$name.csv | cut -c1-200
 }
