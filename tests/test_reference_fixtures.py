@@ -358,7 +358,10 @@ def test_fused_mfma_network_against_reference_outputs():
     """bl_mlp_forward_f16 + bl_sim_finish's heads (networks.Inference(fused=True), the bench's network kernels) with the
     reference's own 512x4 parameters against the f16 values the reference stored for its leaf evaluations (f32 on its CPU path,
     then `.half()`, mcts/__init__.py:131-136).  Tolerance (fp16 autocast vs f32 -- the reference's own GPU/CPU gap): >= 99 % of
-    the finite logits within 3 f16 ulp, none beyond 16; -inf pattern identical; v within 4 f16 ulp on >= 99 %, none beyond 2^-7 abs."""
+    the finite logits within 3 f16 ulp, none beyond 16; -inf pattern identical; v (a tanh: mean |v| 0.26, values near 0 common) never
+    further than 2^-10 from the reference's (measured: 2^-11, for this kernel and for the torch-GEMM plan alike; tools/debug_vstat.py)
+    and within 4 f16 ulp on >= 90 %.  (Round 5 ran this test on `inf(world)`, the fp32 module, by mistake: its 99 % / 4 ulp line was
+    a statement about fp32, not about this kernel.)"""
     from test_network_golden import reference_network, f16bits, plan_decisions
     from boardlaw_amd import networks
     from boardlaw_amd.hex import Hex
@@ -383,7 +386,7 @@ def test_fused_mfma_network_against_reference_outputs():
         assert (dl <= 3).mean() >= 0.99 and dl.max() <= 16, (sim, dl.max(), (dl <= 3).mean())
         dv = _ulp16(got_v, want_v)
         fv = lambda bits: torch.from_numpy(bits.view(np.int16)).view(torch.half).float().numpy()
-        assert (dv <= 4).mean() >= 0.99 and np.abs(fv(got_v) - fv(want_v)).max() <= 2 ** -7, (sim, dv.max())
+        assert (dv <= 4).mean() >= 0.9 and np.abs(fv(got_v) - fv(want_v)).max() <= 2 ** -10, (sim, dv.max(), np.abs(fv(got_v) - fv(want_v)).max())
         checked += len(rows)
     assert checked > B * (T - 1) // 2
 
