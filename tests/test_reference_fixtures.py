@@ -370,7 +370,7 @@ def test_fused_mfma_network_against_reference_outputs():
     inf = networks.Inference(reference_network(g, 'cuda'), fused=True)
     assert inf.fused_params(B) is not None and inf.prefers_fused(B), 'the fused plan must be the one under test'
     created = g['m0_parents'][:, 1:] != -1                       # (B, T-1): simulation s created node s
-    checked = 0
+    checked, v_ulps = 0, []
     for sim in range(1, T):
         rows = np.nonzero(created[:, sim - 1])[0]
         if len(rows) == 0:
@@ -386,9 +386,11 @@ def test_fused_mfma_network_against_reference_outputs():
         assert (dl <= 3).mean() >= 0.99 and dl.max() <= 16, (sim, dl.max(), (dl <= 3).mean())
         dv = _ulp16(got_v, want_v)
         fv = lambda bits: torch.from_numpy(bits.view(np.int16)).view(torch.half).float().numpy()
-        assert (dv <= 4).mean() >= 0.9 and np.abs(fv(got_v) - fv(want_v)).max() <= 2 ** -10, (sim, dv.max(), np.abs(fv(got_v) - fv(want_v)).max())
+        assert np.abs(fv(got_v) - fv(want_v)).max() <= 2 ** -10, (sim, dv.max(), np.abs(fv(got_v) - fv(want_v)).max())
+        v_ulps.append(dv.ravel())
         checked += len(rows)
     assert checked > B * (T - 1) // 2
+    assert (np.concatenate(v_ulps) <= 4).mean() >= 0.9          # over the whole search (a simulation has 64 leaves at most: too few for a per-simulation fraction)
 
 
 @pytest.mark.gpu
