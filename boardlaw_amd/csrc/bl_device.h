@@ -1,4 +1,4 @@
-// bl_device.h -- device helpers shared by the translation units of libboardlaw_amd.so (bl_kernels.hip, bl_expand.hip,
+// bl_device.h -- device helpers shared by the translation units of libboardlaw_amd.so (bl_search.hip, bl_hex.hip, bl_abi.hip, bl_expand.hip, bl_rows.hip,
 // bl_mlp.hip): binary16 conversions, the order-preserving float<->u32 map of the q range, wave-wide DPP reductions,
 // the search view `Search`, the Hex step on a board held in LDS, and the writer of compacted policy rows.
 #pragma once
@@ -256,7 +256,7 @@ __device__ __forceinline__ int hex_step_group(uint8_t* cells, int S, int seat, i
 }
 
 // Hex's step by ONE WAVE on a board in LDS, the flood as a bit-board fill in wave-uniform registers (round 5; the board tiles of
-// bl_kernels.hip do the same with four lanes per env).  hex_step_group's sweeps cost an LDS round trip per cell and neighbour behind an
+// bl_hex.hip do the same with four lanes per env).  hex_step_group's sweeps cost an LDS round trip per cell and neighbour behind an
 // EXEC branch each, and two or more sweeps with a barrier whenever the new stone touches an edge group -- 4 k cycles and up at the END of
 // every descent's dependent chain.  Here: the six neighbours of the new stone are read by six lanes at once; the mover's plain-coloured
 // cells become a bit set by one ballot per 64 cells; the component grows from the stone by 64-bit shifts on uniform values (scalar

@@ -21,7 +21,7 @@
 //  * wait states: the ISA asks for 2 between a VALU write and a DPP read of the same VGPR (no interlock).  The SAFE
 //    variant pads every step with `s_nop 1`; the FAST one with `s_nop 0`, which tools/micro/fold_variants.hip measures
 //    as sufficient on gfx950 (a padded step then takes as long as the hardware-interlocked dependent v_add: 8.8 vs 9.2
-//    cycles).  FAST is used only after bl_selftest() has verified it on the device at hand (bl_kernels.hip).
+//    cycles).  FAST is used only after bl_selftest() has verified it on the device at hand (bl_abi.hip: bl_selftest).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <math.h>
@@ -807,7 +807,7 @@ __global__ void __launch_bounds__(BL_WAVE) fold_selftest_kernel(uint32_t seed, i
 using namespace bl;
 
 // Launches the compact-row kernel; returns BL_ETOOBIG when the shape is outside its template set (the caller then uses
-// the general kernel of bl_kernels.hip).  waves: 1, or 4 = speculative batches for envs whose last descent had at least
+// the general kernel of bl_search.hip).  waves: 1, or 4 = speculative batches for envs whose last descent had at least
 // `deep_thresh` nodes (needs s.fav).
 int bl_expand2_launch(const Search& ss, int sim, const void* rands, int16_t* leaves, void* obs, uint8_t* valid, int32_t* leaf_seats,
                       unsigned long long* counters, int fast, int waves, int deep_thresh, int envs, int help_thresh, hipStream_t stream) {

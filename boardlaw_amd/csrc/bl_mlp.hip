@@ -63,7 +63,7 @@ struct FinArgs {
 #endif
 #define BLM_QSLOTS 64
 #define BLM_QSTRIDE 64
-__device__ __forceinline__ uint32_t enc(float f) {      // order-preserving float -> u32 (as in bl_kernels.hip)
+__device__ __forceinline__ uint32_t enc(float f) {      // order-preserving float -> u32 (as in bl_device.h)
     const uint32_t b = __builtin_bit_cast(uint32_t, f);
     return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
 }
@@ -640,7 +640,7 @@ __global__ void __launch_bounds__(WAVES * 64) mlp_kernel(Params p, FinArgs f) {
         }
         if (tid < ROWS && grow(tid) < Mrows) p.value[grow(tid)] = Out[tid * p.NHpad + p.NH - 1];
     } else {
-        // ---- bl_sim_finish's work for this wave's four envs, operation for operation as in bl_kernels.hip:
+        // ---- bl_sim_finish's work for this wave's four envs, operation for operation as in bl_search.hip:
         // sim_finish_kernel (heads with torch's order; backup cuda.cu:205-236; transition_q's range), but PHASE by phase
         // across the four envs so that their cross-lane exchanges and LDS trips overlap instead of queueing.
         const int A = f.A, T = f.T, Wsm = f.Wsm, iters = f.iters;

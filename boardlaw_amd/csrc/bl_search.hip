@@ -1,4 +1,6 @@
-// bl_kernels.hip -- gfx950 (MI355X, CDNA4) kernels for boardlaw's vectorised-MCTS hot path.
+// bl_search.hip -- the general search kernels of boardlaw's vectorised-MCTS hot path for gfx950 (MI355X, CDNA4): descend / root /
+// backup / transition_q on the reference's arrays, the fused simulation step on them, the finish step, root planting, tree reset --
+// and their C entry points.  (Until round 6 this was bl_kernels.hip, which also held what is now bl_hex.hip and bl_abi.hip.)
 //
 // Written for 64-wide wavefronts: every kernel assigns a GROUP of G lanes (G in {8,16,32,64}, chosen by the host
 // from B and A) to one env, so a wave carries 64/G envs.  The lanes of a group stride the action axis, which makes
@@ -16,9 +18,9 @@
 #include <stdlib.h>
 #include "../../include/boardlaw_amd.h"
 #include "bl_device.h"
+#include "bl_dispatch.h"
 
 #pragma clang fp contract(off)
-
 
 namespace bl {
 
@@ -562,303 +564,6 @@ __global__ void __launch_bounds__(256) backup_kernel(const uint16_t* v, uint16_t
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// Hex.  Cell codes and rules: boardlaw/hex/cpp/cuda.cu:8-16,76-137; flood cuda.cu:18-74.
-// ------------------------------------------------------------------------------------------------------------------
-
-template <int G>
-__global__ void __launch_bounds__(BL_WAVE) hex_step_kernel(uint8_t* board, const int32_t* seats, const int32_t* actions,
-                                                           float* rewards, int B, int S) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int A = S * S, grp = threadIdx.x / G, gl = threadIdx.x % G;
-    const int b = blockIdx.x * (BL_WAVE / G) + grp;
-    const bool go = b < B;
-    uint8_t* cells = (uint8_t*)smem + (size_t)grp * ((A + 15) & ~15);
-    uint8_t* src = board + (long)b * A;
-    if (go) for (int a = gl; a < A; a += G) cells[a] = src[a];
-    __syncthreads();
-    const int win = hex_step_group<G>(cells, S, go ? seats[b] : 0, go ? actions[b] : 0, go, gl);
-    if (go) {
-        for (int a = gl; a < A; a += G) src[a] = cells[a];
-        if (gl == 0) { rewards[2 * b] = (float)win; rewards[2 * b + 1] = (float)(-win); }
-    }
-}
-
-// Hex.step as one launch (hex/__init__.py:161-195 with reset=True): clone the board, step it, terminal = any reward > 0,
-// wipe finished boards, pass the move to the other seat (seat 0 after a finished game).
-template <int G>
-__global__ void __launch_bounds__(BL_WAVE) hex_world_step_kernel(const uint8_t* board_in, const int32_t* seats_in, const void* actions,
-                                                                 int actions_i64, uint8_t* board_out, int32_t* seats_out,
-                                                                 float* rewards, uint8_t* terminal, int B, int S) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int A = S * S, grp = threadIdx.x / G, gl = threadIdx.x % G;
-    const int b = blockIdx.x * (BL_WAVE / G) + grp;
-    const bool go = b < B;
-    uint8_t* cells = (uint8_t*)smem + (size_t)grp * ((A + 15) & ~15);
-    const uint8_t* src = board_in + (long)b * A;
-    if (go) for (int a = gl; a < A; a += G) cells[a] = src[a];
-    int seat = 0, action = 0;
-    if (go) { seat = seats_in[b]; action = actions_i64 ? (int)((const long long*)actions)[b] : ((const int32_t*)actions)[b]; }
-    __syncthreads();
-    const int win = hex_step_group<G>(cells, S, seat, action, go, gl);
-    if (go) {
-        uint8_t* dst = board_out + (long)b * A;
-        for (int a = gl; a < A; a += G) dst[a] = win ? (uint8_t)0 : cells[a];
-        if (gl == 0) {
-            rewards[2 * b] = (float)win; rewards[2 * b + 1] = (float)(-win);
-            terminal[b] = win != 0;
-            seats_out[b] = win ? 0 : 1 - seat;
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------------------------------
-// Round 5: the board kernels as HBM streams.  The kernels above give every env a group of lanes that fetches its own board byte by
-// byte -- fine inside a search (one launch per move, 4096 boards) and 9-13 % of the HBM roofline on a million boards
-// (bench.py `hex_kernels`).  Here a workgroup of 256 threads takes E = 256 / LPE CONSECUTIVE envs: their boards are one
-// contiguous, 16-byte-aligned run of E * A bytes (E * A is a multiple of 16 for E = 64 and 16), which goes into LDS as 16-byte
-// loads, is stepped there by LPE lanes per env (hex_step_group, wave-scope synchronisation: an env's lanes share a wave and the
-// waves of the workgroup never wait for each other inside the flood), and leaves as 16-byte stores.  Same cell arithmetic, same
-// results; `world` adds Hex.step's tail (hex/__init__.py:183-190: wipe finished boards, pass the move on).
-// ------------------------------------------------------------------------------------------------------------------
-// Column masks of an S x S board as bit sets over the cells (bit a = cell a, row-major): cells that have a left / a right neighbour.
-struct HexMasks { uint32_t not_first[8], not_last[8]; };
-
-// Hex's step on a board in LDS by FOUR lanes, the flood as a bit-board fill.  The sweeps of hex_step_group cost a pass over the board
-// per propagation step with LDS round trips in it; here the four lanes of an env collect the cells of the mover's plain colour as a
-// bit set (NW 32-bit words, lane l the cells 4 i + l, OR-ed over the quad with two DPP moves), grow the component from the new stone
-// with shifts -- the six neighbours of cell a are a -+ S, a -+ 1 and a -+ (S - 1), the latter four behind the column masks -- until
-// it stops growing, and write the label into its cells.  Same component (cuda.cu:18-74 relabels the 6-connected plain cells reachable
-// from the new stone; the net effect is order-independent), same bytes.  A <= 32 NW.
-template <int NW>
-__device__ __forceinline__ int hex_step_quad(uint8_t* cells, int S, int seat, int action, bool go, int gl, const HexMasks& hm) {
-    const int A = S * S;
-    const float invS = 1.0f / (float)S;
-    int label = 0, win = 0, start = 0, plain = 0;
-    if (go && gl == 0) {
-        const int qd = (int)(((float)action + 0.5f) * invS), rm = action - qd * S;
-        const int row = seat == 0 ? qd : rm, col = seat == 0 ? rm : qd;   // white plays transposed, cuda.cu:88-91
-        unsigned adj = 0;
-        const int dr[6] = {-1, -1, 0, 0, +1, +1}, dc[6] = {0, +1, -1, +1, -1, 0};
-#pragma unroll
-        for (int k = 0; k < 6; k++) {
-            const int r = row + dr[k], c = col + dc[k];
-            int code;
-            if (r < 0) code = TOP; else if (r >= S) code = BOT; else if (c < 0) code = LEFT; else if (c >= S) code = RIGHT;
-            else code = cells[r * S + c];
-            adj |= 1u << code;
-        }
-        const bool aT = adj & (1u << TOP), aB = adj & (1u << BOT), aL = adj & (1u << LEFT), aR = adj & (1u << RIGHT);
-        if (seat) { if (aL && aR) win = -1; label = aL ? LEFT : (aR ? RIGHT : WHITE); plain = WHITE; }
-        else      { if (aT && aB) win = +1; label = aT ? TOP : (aB ? BOT : BLACK); plain = BLACK; }
-        start = row * S + col;
-        if (label < TOP) cells[start] = (uint8_t)plain;                  // no flood: the plain colour (cuda.cu:134)
-    }
-    // lane 0 of the quad -> all four (quad_perm [0,0,0,0])
-    label = dpp_i<0x00, 0xf>(label, label); win = dpp_i<0x00, 0xf>(win, win);
-    plain = dpp_i<0x00, 0xf>(plain, plain); start = dpp_i<0x00, 0xf>(start, start);
-    const bool flooding = go && label >= TOP;
-    if (__any(flooding)) {
-        uint32_t P[NW], M[NW];
-#pragma unroll
-        for (int w = 0; w < NW; w++) {
-            // branch-free: all eight reads of a word in flight at once (a read beyond the board -- at most 31 bytes, into the next
-            // env's cells or the pad behind the last one -- is masked out by `a < A`); as `if (...) bits |= ...` the compiler put every
-            // cell behind its own EXEC branch with a wait per read: ten instructions and an LDS round trip per cell
-            uint32_t bits = 0;
-            uint8_t c[8];
-#pragma unroll
-            for (int i = 0; i < 8; i++) c[i] = cells[32 * w + 4 * i + gl];
-#pragma unroll
-            for (int i = 0; i < 8; i++) {
-                const int a = 32 * w + 4 * i + gl;
-                bits |= (uint32_t)((c[i] == (uint8_t)plain) & (a < A)) << (4 * i + gl);
-            }
-            if (!flooding) bits = 0;
-            bits |= (uint32_t)dpp_i<0xB1, 0xf>(0, (int)bits);            // quad_perm [1,0,3,2]
-            bits |= (uint32_t)dpp_i<0x4E, 0xf>(0, (int)bits);            // quad_perm [2,3,0,1]
-            P[w] = bits;
-            M[w] = (flooding && (start >> 5) == w) ? 1u << (start & 31) : 0u;
-        }
-        // shl / shr of an NW-word bit set by k in 1..31 (k = 0 only ever meets an empty set: S = 1)
-        auto shl = [&](const uint32_t (&x)[NW], int k, uint32_t (&y)[NW]) {
-#pragma unroll
-            for (int w = 0; w < NW; w++) y[w] = __builtin_amdgcn_alignbit(x[w], w ? x[w - 1] : 0u, 32 - k);
-        };
-        auto shr = [&](const uint32_t (&x)[NW], int k, uint32_t (&y)[NW]) {
-#pragma unroll
-            for (int w = 0; w < NW; w++) y[w] = __builtin_amdgcn_alignbit(w + 1 < NW ? x[w + 1] : 0u, x[w], k);
-        };
-        for (int it = 0; it < A; it++) {
-            // neighbours of the set M: L = (M with a right neighbour) << 1, R = (M with a left neighbour) >> 1, and the rows above and
-            // below as ONE shift each -- cell a - S and a - S + 1 are (M | L) >> S, cell a + S and a + S - 1 are (M | R) << S
-            uint32_t L[NW], R[NW], U[NW], D[NW], t[NW];
-#pragma unroll
-            for (int w = 0; w < NW; w++) { U[w] = M[w] & hm.not_last[w]; D[w] = M[w] & hm.not_first[w]; }
-            shl(U, 1, L);
-            shr(D, 1, R);
-#pragma unroll
-            for (int w = 0; w < NW; w++) { U[w] = M[w] | L[w]; D[w] = M[w] | R[w]; }
-            shr(U, S, t);
-            shl(D, S, U);
-            uint32_t grew = 0;
-#pragma unroll
-            for (int w = 0; w < NW; w++) { const uint32_t nw = (L[w] | R[w] | t[w] | U[w]) & P[w] & ~M[w]; M[w] |= nw; grew |= nw; }
-            if (!__any(grew != 0)) break;
-        }
-#pragma unroll
-        for (int w = 0; w < NW; w++) {
-            if (32 * (w + 1) <= A) {
-                // a word that lies inside the board: every lane rewrites its eight cells, select(label, old value) -- two instructions a
-                // cell and no EXEC juggling (a lane's cells are its own: nobody else writes them; envs that do not flood have M = 0)
-                uint8_t c[8];
-#pragma unroll
-                for (int i = 0; i < 8; i++) c[i] = cells[32 * w + 4 * i + gl];
-#pragma unroll
-                for (int i = 0; i < 8; i++) cells[32 * w + 4 * i + gl] = ((M[w] >> (4 * i + gl)) & 1u) ? (uint8_t)label : c[i];
-            } else if (32 * w < A) {
-#pragma unroll
-                for (int i = 0; i < 8; i++) {
-                    const int a = 32 * w + 4 * i + gl;
-                    if (a < A && ((M[w] >> (4 * i + gl)) & 1u)) cells[a] = (uint8_t)label;
-                }
-            }
-        }
-    }
-    return win;
-}
-
-template <int NW>
-__global__ void __launch_bounds__(256) hex_step_tile_kernel(const uint8_t* board_in, uint8_t* board_out, const int32_t* seats_in,
-                                                            const void* actions, int actions_i64, int32_t* seats_out, float* rewards,
-                                                            uint8_t* terminal, int B, int S, int world, const HexMasks hm) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int LPE = 4, E = 256 / LPE;
-    const int A = S * S, tid = threadIdx.x;
-    const long e0 = (long)blockIdx.x * E;
-    const int nE = (int)((long)B - e0 < (long)E ? (long)B - e0 : (long)E);
-    const long start = e0 * A;
-    const int bytes = nE * A, n16 = bytes >> 4;
-    uint8_t* all = (uint8_t*)smem;
-    {
-        const uint4* src = (const uint4*)(board_in + start);
-        for (int i = tid; i < n16; i += 256) ((uint4*)all)[i] = src[i];
-        for (int i = (n16 << 4) + tid; i < bytes; i += 256) all[i] = board_in[start + i];
-    }
-    const int env = tid / LPE, gl = tid % LPE;
-    const bool go = env < nE;
-    const long b = e0 + env;
-    int seat = 0, action = 0;
-    if (go) { seat = seats_in[b]; action = actions_i64 ? (int)((const long long*)actions)[b] : ((const int32_t*)actions)[b]; }
-    __syncthreads();
-    uint8_t* cells = all + (size_t)env * A;
-    const int win = hex_step_quad<NW>(cells, S, seat, action, go, gl, hm);
-    if (go) {
-        if (world && win) for (int a = gl; a < A; a += LPE) cells[a] = 0;
-        if (gl == 0) {
-            rewards[2 * b] = (float)win; rewards[2 * b + 1] = (float)(-win);
-            if (world) { terminal[b] = win != 0; seats_out[b] = win ? 0 : 1 - seat; }
-        }
-    }
-    __syncthreads();
-    {
-        uint4* dst = (uint4*)(board_out + start);
-        for (int i = tid; i < n16; i += 256) dst[i] = ((const uint4*)all)[i];
-        for (int i = (n16 << 4) + tid; i < bytes; i += 256) board_out[start + i] = all[i];
-    }
-}
-
-// observe (+ Hex.valid) the same way: 64 consecutive envs per workgroup, boards staged in LDS with 16-byte loads (the transposed
-// read of a white mover's board is then an LDS gather, not an HBM one), every thread four consecutive cells at a time: two 16-byte
-// stores of f32 planes and one 4-byte store of the mask (a 64-env run starts at a multiple of 64 cells: both are aligned).
-__global__ void __launch_bounds__(256) hex_observe_tile_kernel(const uint8_t* board, const int32_t* seats, float* obs, uint8_t* valid, int B, int S) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int E = 64;
-    const int A = S * S, tid = threadIdx.x;
-    const long e0 = (long)blockIdx.x * E;
-    const int nE = (int)((long)B - e0 < (long)E ? (long)B - e0 : (long)E);
-    const long start = e0 * A;
-    const int bytes = nE * A, n16 = bytes >> 4;
-    uint8_t* all = (uint8_t*)smem;
-    uint8_t* flips = all + (((size_t)E * A + 15) & ~(size_t)15);
-    {
-        const uint4* src = (const uint4*)(board + start);
-        for (int i = tid; i < n16; i += 256) ((uint4*)all)[i] = src[i];
-        for (int i = (n16 << 4) + tid; i < bytes; i += 256) all[i] = board[start + i];
-        if (tid < nE) flips[tid] = seats[e0 + tid] == 1;
-    }
-    __syncthreads();
-    const float invA = 1.0f / (float)A, invS = 1.0f / (float)S;
-    const int quads = (bytes + 3) >> 2;
-    float* obase = obs + start * 2;
-    for (int q = tid; q < quads; q += 256) {
-        float o[8];
-        uint32_t vm = 0;
-        // the quad's first cell by division (idx < 64 * 1024: exact in f32), the other three by stepping (cell, row, column) with wrap-around
-        int idx = 4 * q;
-        int e = (int)(((float)idx + 0.5f) * invA), a = idx - e * A;
-        int i = (int)(((float)a + 0.5f) * invS), j = a - i * S;
-        bool flip = flips[e] != 0;
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            o[2 * k] = 0.f; o[2 * k + 1] = 0.f;
-            if (idx < bytes) {
-                const int c = all[e * A + (flip ? j * S + i : a)];
-                const int color = c < 7 ? (0x1412 >> (2 * c)) & 3 : 2;  // color_of as a table: codes 1,3,4 -> 0; 2,5,6 -> 1; anything else -> 2
-                if (color < 2) { if ((flip ? 1 - color : color) == 0) o[2 * k] = 1.f; else o[2 * k + 1] = 1.f; }
-                else vm |= 1u << (8 * k);
-            }
-            idx++; a++; j++;
-            if (j == S) { j = 0; i++; }
-            if (a == A) { a = 0; i = 0; j = 0; e++; flip = (e < nE) && flips[e] != 0; }
-        }
-        if (4 * q + 3 < bytes) {
-            ((float4*)obase)[2 * q] = make_float4(o[0], o[1], o[2], o[3]);
-            ((float4*)obase)[2 * q + 1] = make_float4(o[4], o[5], o[6], o[7]);
-            if (valid) *(uint32_t*)(valid + start + 4 * q) = vm;
-        } else {
-            for (int k = 0; k < 4 && 4 * q + k < bytes; k++) {
-                obase[2 * (4 * q + k)] = o[2 * k]; obase[2 * (4 * q + k) + 1] = o[2 * k + 1];
-                if (valid) valid[start + 4 * q + k] = (vm >> (8 * k)) & 1;
-            }
-        }
-    }
-}
-
-// observe, cuda.cu:154-195: mover sees itself in channel 0, playing top-to-bottom.
-
-__global__ void __launch_bounds__(256) hex_observe_kernel(const uint8_t* board, const int32_t* seats, float2* obs, long cells, int S) {
-    const int A = S * S;
-    const float invS = 1.0f / (float)S;
-    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < cells; idx += (long)gridDim.x * blockDim.x) {
-        const long b = idx / A;
-        const int a = (int)(idx - b * A);
-        const int i = (int)(((float)a + 0.5f) * invS), j = a - i * S;
-        const bool flip = seats[b] == 1;
-        const int color = color_of(board[b * A + (flip ? j * S + i : a)]);
-        float2 o = make_float2(0.f, 0.f);
-        if (color < 2) { if ((flip ? 1 - color : color) == 0) o.x = 1.f; else o.y = 1.f; }
-        obs[idx] = o;
-    }
-}
-
-// observe + Hex.valid (hex/__init__.py:154-159: (obs == 0).all(-1)) in one pass
-__global__ void __launch_bounds__(256) hex_observe_valid_kernel(const uint8_t* board, const int32_t* seats, float2* obs, uint8_t* valid, long cells, int S) {
-    const int A = S * S;
-    const float invS = 1.0f / (float)S;
-    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < cells; idx += (long)gridDim.x * blockDim.x) {
-        const long b = idx / A;
-        const int a = (int)(idx - b * A);
-        const int i = (int)(((float)a + 0.5f) * invS), j = a - i * S;
-        const bool flip = seats[b] == 1;
-        const int color = color_of(board[b * A + (flip ? j * S + i : a)]);
-        float2 o = make_float2(0.f, 0.f);
-        if (color < 2) { if ((flip ? 1 - color : color) == 0) o.x = 1.f; else o.y = 1.f; }
-        obs[idx] = o;
-        valid[idx] = color == 2;
-    }
-}
-
-// ------------------------------------------------------------------------------------------------------------------
 // Fused simulation step for Hex: mcts/__init__.py:113-129 + hex/__init__.py:148-195.
 // ------------------------------------------------------------------------------------------------------------------
 
@@ -1259,51 +964,6 @@ __global__ void __launch_bounds__(BL_WAVE) compact_rows_kernel(Search s, const i
     if (lane == 0) s.nk[node] = (int16_t)count;
 }
 
-// ReZero residual under fp16 autocast, fused (networks.py:17-18): x_out = x + alpha*y with torch's rounding points --
-// alpha (an f32 0-dim parameter) is cast to the tensors' dtype f16, the product is rounded to f16, the sum is rounded
-// to f16 -- plus relu(x_out) for the next block, 8 halves per thread.
-__global__ void __launch_bounds__(256) rezero_relu_kernel(const uint16_t* x, const uint16_t* y, const float* alpha,
-                                                         uint16_t* x_out, uint16_t* relu_out, long n8, long n) {
-    const float al = h2f(f2h(*alpha));
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long)gridDim.x * blockDim.x) {
-        const uint4 xv = ((const uint4*)x)[i], yv = ((const uint4*)y)[i];
-        const uint32_t xs[4] = {xv.x, xv.y, xv.z, xv.w}, ys[4] = {yv.x, yv.y, yv.z, yv.w};
-        uint32_t o[4], r[4];
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            uint32_t ow = 0, rw = 0;
-#pragma unroll
-            for (int hlf = 0; hlf < 2; hlf++) {
-                const uint16_t xb = (uint16_t)(xs[j] >> (16 * hlf)), yb = (uint16_t)(ys[j] >> (16 * hlf));
-                const uint16_t ob = f2h(h2f(xb) + h2f(f2h(al * h2f(yb))));
-                const uint16_t rb = (ob & 0x8000u) ? (uint16_t)((ob & 0x7fffu) > 0x7c00u ? ob : 0) : ob;   // relu keeps NaN
-                ow |= (uint32_t)ob << (16 * hlf); rw |= (uint32_t)rb << (16 * hlf);
-            }
-            o[j] = ow; r[j] = rw;
-        }
-        ((uint4*)x_out)[i] = make_uint4(o[0], o[1], o[2], o[3]);
-        ((uint4*)relu_out)[i] = make_uint4(r[0], r[1], r[2], r[3]);
-    }
-    // tail (n not a multiple of 8)
-    for (long i = n8 * 8 + (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
-        const uint16_t ob = f2h(h2f(x[i]) + h2f(f2h(al * h2f(y[i]))));
-        x_out[i] = ob;
-        relu_out[i] = (ob & 0x8000u) ? (uint16_t)((ob & 0x7fffu) > 0x7c00u ? ob : 0) : ob;
-    }
-}
-
-// The same ReZero tail in fp32 (the root evaluation runs outside autocast, mcts/__init__.py:72-76): x_out = x + alpha*y
-// with the product and the sum rounded separately, as torch's mul and add kernels do, plus relu(x_out).
-__global__ void __launch_bounds__(256) rezero_relu_f32_kernel(const float* x, const float* y, const float* alpha,
-                                                             float* x_out, float* relu_out, long n) {
-    const float al = *alpha;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
-        const float o = x[i] + al * y[i];
-        x_out[i] = o;
-        relu_out[i] = (o < 0.f) ? 0.f : o;          // keeps NaN, like torch's relu
-    }
-}
-
 // ------------------------------------------------------------------------------------------------------------------
 // bl_sim_plant_root: what MCTS.initialize does with the root network's fp32 pre-head outputs (mcts/__init__.py:72-80,
 // 13-24; heads.py:101-104,122-142), one wave per env:
@@ -1514,115 +1174,6 @@ __global__ void __launch_bounds__(BL_WAVE) sim_n_leaves_kernel(const int16_t* pa
     count = wave_sum_i32(count);
     if (lane == 0) out[b] = count;
 }
-
-// actions ~ Categorical(probs / sum(probs)) by inverse CDF, one uniform per env: the first action whose running total
-// (ascending a, f32) reaches u * total, among those with positive probability; the last such action if rounding leaves the
-// running total short.  One wave per env.
-// Up to BL_COPY_MAX device-to-device copies as one launch: blockIdx.y = the copy (rows x row_bytes, each end with its own
-// pitch), its blocks stride over 16-byte words when both ends and pitches allow it, else over 2-byte or 1-byte units.
-struct CopyBatch { bl_copy_t it[BL_COPY_MAX]; };
-template <typename U>
-__device__ __forceinline__ void copy_units(const bl_copy_t& c, size_t tid, size_t nth) {
-    const size_t w = c.row_bytes / sizeof(U), total = w * c.rows;
-    const uint8_t* src = (const uint8_t*)c.src; uint8_t* dst = (uint8_t*)c.dst;
-    if (c.rows == 1) { for (size_t i = tid; i < w; i += nth) ((U*)dst)[i] = ((const U*)src)[i]; return; }
-    for (size_t i = tid; i < total; i += nth) {
-        const size_t r = i / w, k = i - r * w;
-        ((U*)(dst + r * c.dst_pitch))[k] = ((const U*)(src + r * c.src_pitch))[k];
-    }
-}
-__global__ void __launch_bounds__(256) copy_many_kernel(CopyBatch cb) {
-    const bl_copy_t& c = cb.it[blockIdx.y];
-    const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x, nth = (size_t)gridDim.x * blockDim.x;
-    const unsigned long long bits = (unsigned long long)(uintptr_t)c.src | (unsigned long long)(uintptr_t)c.dst | c.row_bytes |
-                                    (c.rows > 1 ? (c.src_pitch | c.dst_pitch) : 0ull);
-    if ((bits & 15) == 0) copy_units<uint4>(c, tid, nth);
-    else if ((bits & 1) == 0) copy_units<uint16_t>(c, tid, nth);
-    else copy_units<uint8_t>(c, tid, nth);
-}
-
-__global__ void __launch_bounds__(BL_WAVE) draw_actions_kernel(const uint16_t* probs, const float* u, long long* actions, int A) {
-    const int b = blockIdx.x, lane = threadIdx.x;
-    const uint16_t* p = probs + (long)b * A;
-    float carry = 0.f, total = 0.f;
-    for (int a0 = 0; a0 < A; a0 += BL_WAVE) total += (a0 + lane < A) ? h2f(p[a0 + lane]) : 0.f;
-    for (int m = 32; m > 0; m >>= 1) total += __shfl_xor(total, m, BL_WAVE);
-    const float target = u[b] * total;
-    int pick = -1, lastpos = -1;
-    for (int a0 = 0; a0 < A; a0 += BL_WAVE) {
-        const int a = a0 + lane;
-        const float v = a < A ? h2f(p[a]) : 0.f;
-        float x = v;
-        for (int d = 1; d < BL_WAVE; d <<= 1) { const float y = __shfl_up(x, d, BL_WAVE); if (lane >= d) x += y; }
-        x += carry;
-        const unsigned long long pos = __ballot(v > 0.f), hit = __ballot(v > 0.f && x >= target);
-        if (pick < 0 && hit) pick = a0 + __builtin_ctzll(hit);
-        if (pos) lastpos = a0 + 63 - __builtin_clzll(pos);
-        carry = __shfl(x, BL_WAVE - 1, BL_WAVE);
-    }
-    if (lane == 0) actions[b] = pick >= 0 ? pick : (lastpos >= 0 ? lastpos : 0);
-}
-
-// ------------------------------------------------------------------------------------------------------------------
-// MCTSAgent's action draw (mcts/__init__.py:221) as torch computes it, in ONE launch, one wave per env:
-//     torch.distributions.Categorical(logits=x).sample(),  x = root logits .float()
-//   = argmax(softmax(x - x.logsumexp(-1, keepdim=True)) / q),  q = empty_like(probs).exponential_(1)      [torch.multinomial, one draw]
-// operation for operation with the launches it replaces (amax; |m| == inf -> 0; sub; exp; sum -- torch_row_sum; log; add; sub;
-// the persistent softmax: lane l holds elements l, l + W, per-lane max and exp-sum in order, XOR butterflies with offsets W/2 .. 1;
-// two IEEE divisions; argmax with the lower index on ties).  q is drawn by torch's own exponential_ kernel, so the generator is
-// consumed exactly as by the reference's call.  A < 128.  tests/test_rng_stream.py: the actions equal torch's on the same q.
-// ------------------------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(BL_WAVE) categorical_kernel(const uint16_t* logits, const float* q, long long* actions, int A, int W, int iters, int Wr) {
-    __shared__ float tbuf[128];
-    const int b = blockIdx.x, lane = threadIdx.x;
-    const uint16_t* lrow = logits + (long)b * A;
-    const float* qrow = q + (long)b * A;
-    float x[2], qq[2];
-#pragma unroll
-    for (int it = 0; it < 2; it++) {
-        const int a = lane + it * W;
-        const bool in = lane < W && it < iters && a < A;
-        x[it] = in ? h2f(lrow[a]) : -INFINITY;
-        qq[it] = in ? qrow[a] : 1.f;
-    }
-    // logsumexp (ReduceOps.cpp: logsumexp_out_impl)
-    float m = wave_max_f32((x[0] > x[1]) ? x[0] : x[1]);
-    if (fabsf(m) == INFINITY) m = 0.f;
-#pragma unroll
-    for (int it = 0; it < 2; it++) {
-        const int a = lane + it * W;
-        if (lane < W && it < iters && a < A) tbuf[a] = expf(x[it] - m);
-    }
-    __syncthreads();
-    const float own = lane < Wr ? tbuf[lane] : 0.f, second = (lane < Wr && lane + Wr < A) ? tbuf[lane + Wr] : 0.f;
-    const float lse = logf(torch_row_sum(own, second, Wr)) + m;
-    // softmax(x - lse) (PersistentSoftmax.cuh: softmax_warp_forward, is_log_softmax = false)
-    float y[2], e[2];
-    y[0] = x[0] - lse; y[1] = x[1] - lse;
-    float mx = y[0];
-    if (iters > 1) mx = (mx > y[1]) ? mx : y[1];
-    for (int off = W / 2; off > 0; off /= 2) { const float o = __shfl_xor(mx, off, BL_WAVE); mx = (mx < o) ? o : mx; }
-    float sum = 0.f;
-    e[0] = expf(y[0] - mx); sum += e[0];
-    if (iters > 1) { e[1] = expf(y[1] - mx); sum += e[1]; } else e[1] = 0.f;
-    for (int off = W / 2; off > 0; off /= 2) sum = sum + __shfl_xor(sum, off, BL_WAVE);
-    // argmax(probs / q), lower index on ties (ArgMaxOps)
-    float best = -INFINITY; int besta = 0x7fffffff;
-#pragma unroll
-    for (int it = 0; it < 2; it++) {
-        const int a = lane + it * W;
-        if (lane < W && it < iters && a < A) {
-            const float r = (e[it] / sum) / qq[it];
-            if (r > best || (r == best && a < besta) || r != r) { best = r; besta = a; }
-        }
-    }
-    for (int off = 32; off > 0; off >>= 1) {
-        const float ob = __shfl_xor(best, off, BL_WAVE); const int oa = __shfl_xor(besta, off, BL_WAVE);
-        if (ob > best || (ob == best && oa < besta)) { best = ob; besta = oa; }
-    }
-    if (lane == 0) actions[b] = besta == 0x7fffffff ? 0 : besta;
-}
-
 __global__ void __launch_bounds__(256) zero_words_kernel(uint32_t* p, int n, uint32_t word) {
     for (int i = threadIdx.x; i < n; i += blockDim.x) p[i] = word;
 }
@@ -1634,96 +1185,13 @@ __global__ void __launch_bounds__(256) zero_words_kernel(uint32_t* p, int n, uin
 // =====================================================================================================================
 using namespace bl;
 
-// Lanes per env in the general kernels.  `forced` (bl_tune_t.group: 8|16|32|64, 0 = none) overrides the heuristic below.
-static int pick_group(int B, int A, int forced = 0) {
-    const int f = forced;
-    if ((f == 8 || f == 16 || f == 32 || f == 64) && (A + f - 1) / f <= 16) return f;
-    // One wave per env whenever the action count allows (A <= 64 x 16): that is the DPP path (no LDS, no barriers,
-    // serial folds across lanes).  Measured on MI355X at 9x9 it beats the narrower LDS-fold groups at every batch size
-    // tried (4096 ... 32768 envs: 1.2-1.6x), because a descent is one long dependent chain and what hides its latency
-    // is other waves, not busier lanes.  The narrower groups remain for BL_FORCE_GROUP experiments and for parity tests.
-    int G = 64;
-    (void)B;
-    return G;
-}
-
-static int pick_k(int A, int G) {
-    const int need = (A + G - 1) / G;
-    const int ks[7] = {2, 3, 4, 6, 8, 12, 16};
-    for (int i = 0; i < 7; i++) if (need <= ks[i]) return ks[i];
-    return -1;
-}
-
-static int check_launch() { return hipGetLastError() == hipSuccess ? BL_OK : BL_ELAUNCH; }
-
-#define BL_DISPATCH_K(g, K, CALL)                                                                    \
-    switch (K) {                                                                                     \
-        case 2: { CALL(g, 2); } break;   case 3: { CALL(g, 3); } break;   case 4: { CALL(g, 4); } break; \
-        case 6: { CALL(g, 6); } break;   case 8: { CALL(g, 8); } break;   case 12: { CALL(g, 12); } break; \
-        case 16: { CALL(g, 16); } break; default: return BL_ETOOBIG;                                 \
-    }
-#define BL_DISPATCH_GK(G, K, CALL)                                                                   \
-    switch (G) {                                                                                     \
-        case 8: BL_DISPATCH_K(8, K, CALL) break;    case 16: BL_DISPATCH_K(16, K, CALL) break;        \
-        case 32: BL_DISPATCH_K(32, K, CALL) break;  case 64: BL_DISPATCH_K(64, K, CALL) break;        \
-        default: return BL_ETOOBIG;                                                                  \
-    }
-
 int bl_expand2_launch(const Search& ss, int sim, const void* rands, int16_t* leaves, void* obs, uint8_t* valid, int32_t* leaf_seats,
                       unsigned long long* counters, int fast, int waves, int deep_thresh, int envs, int help_thresh, hipStream_t stream);     // bl_expand.hip
 int bl_fold_selftest(int use_fast, hipStream_t stream);
 int bl_expand_rows_launch(const Search& ss, int sim, const void* rands, int16_t* leaves, void* obs, uint8_t* valid, int32_t* leaf_seats,
                           int waves, hipStream_t stream);      // bl_rows.hip
 
-namespace bl {
-__global__ void __launch_bounds__(256) powf2_kernel(const float* x, float* out, long n) {
-    const long i = (long)blockIdx.x * 256 + threadIdx.x;
-    if (i < n) out[i] = g_denominator(x[i], 1);
-}
-}  // namespace bl
-
 extern "C" {
-
-int bl_abi_version(void) { return 4; }
-
-const char* bl_strerror(int code) {
-    switch (code) {
-        case BL_OK: return "ok";
-        case BL_EINVAL: return "invalid argument (null pointer or non-positive size)";
-        case BL_ETOOBIG: return "size beyond kernel limits (A <= 1024, T <= 32767, S <= 8, boardsize <= 32)";
-        case BL_ELAUNCH: return "HIP kernel launch failed";
-        default: return "unknown error";
-    }
-}
-
-int bl_exp_table_host(float* t) {
-    if (!t) return BL_EINVAL;
-    for (uint32_t i = 0; i < 65536; i++) {
-        uint16_t h = (uint16_t)i;
-        // binary16 -> binary32 (exact)
-        uint32_t sign = (uint32_t)(h & 0x8000u) << 16, e = (h >> 10) & 0x1f, mnt = h & 0x3ffu, bits;
-        if (e == 0) {
-            if (mnt == 0) bits = sign;
-            else { int sh = -1; do { sh++; mnt <<= 1; } while (!(mnt & 0x400u)); bits = sign | ((uint32_t)(112 - sh) << 23) | ((mnt & 0x3ffu) << 13); }
-        } else if (e == 31) bits = sign | 0x7f800000u | (mnt << 13);
-        else bits = sign | ((e + 112) << 23) | (mnt << 13);
-        float x; memcpy(&x, &bits, 4);
-        t[i] = expf(x);
-    }
-    return BL_OK;
-}
-
-int bl_qrange_decode(const uint32_t* st, float* mm) {
-    if (!st || !mm) return BL_EINVAL;
-    uint32_t a = 0, b = 0;
-    for (int i = 0; i < BL_QSLOTS; i++) {
-        const uint32_t x = st[BL_QSTRIDE * i] ^ BL_QBIAS, y = st[BL_QSTRIDE * i + 1] ^ BL_QBIAS;       // memory words -> unsigned codes
-        if (x > a) a = x;
-        if (y > b) b = y;
-    }
-    mm[0] = dec(~a); mm[1] = dec(b);
-    return BL_OK;
-}
 
 int bl_mcts_qrange(const void* w, const int16_t* n, int B, int T, int S, uint32_t* st, bl_stream_t stream) {
     if (!w || !n || !st || B <= 0 || T <= 0 || S <= 0) return BL_EINVAL;
@@ -1800,107 +1268,6 @@ int bl_mcts_backup(const void* v, void* w, int16_t* n, const void* rewards, cons
     const long threads = (long)B * S;
     hipLaunchKernelGGL(backup_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                        (const uint16_t*)v, (uint16_t*)w, n, (const uint16_t*)rewards, parents, terminal, leaves, B, T, S);
-    return check_launch();
-}
-
-// From how many envs the board kernels run as LDS-staged tiles of 64 consecutive envs (tools/hex_tile_ab.py, profiles/r05_hex_tiles.txt,
-// 11x11, us per call lanes-per-env / tiled): step 7.4 / 6.1 at 1024 envs, 250 / 72 at 2^20 -- always; observe + valid 3.1 / 12.7 at
-// 4096, 19.6 / 20.5 at 65536, 119 / 70 at 262144, 518 / 258 at 2^20 -- a tile's 30 dependent quads per thread are its latency floor,
-// so only from 2^17 envs on.
-#define BL_HEX_TILE_MIN_ENVS 1
-#define BL_HEX_OBSERVE_TILE_MIN_ENVS (1 << 17)
-static void hex_tile_launch(const uint8_t* board_in, uint8_t* board_out, const int32_t* seats_in, const void* actions, int actions_i64,
-                            int32_t* seats_out, float* rewards, uint8_t* terminal, int B, int S, int world, hipStream_t stream) {
-    const int A = S * S;          // <= 256: the callers check S <= 16
-    bl::HexMasks hm{};
-    for (int a = 0; a < A; a++) {
-        if (a % S > 0) hm.not_first[a >> 5] |= 1u << (a & 31);
-        if (a % S < S - 1) hm.not_last[a >> 5] |= 1u << (a & 31);
-    }
-    const dim3 grid((unsigned)((B + 63) / 64));
-    const size_t lds = (size_t)((64 * A + 15) & ~15) + 32;      // + the scan's over-read behind the last env
-    if (A <= 128)
-        hipLaunchKernelGGL((hex_step_tile_kernel<4>), grid, dim3(256), lds, stream, board_in, board_out, seats_in, actions, actions_i64, seats_out,
-                           rewards, terminal, B, S, world, hm);
-    else
-        hipLaunchKernelGGL((hex_step_tile_kernel<8>), grid, dim3(256), lds, stream, board_in, board_out, seats_in, actions, actions_i64, seats_out,
-                           rewards, terminal, B, S, world, hm);
-}
-
-int bl_hex_step_tiled(uint8_t* board, const int32_t* seats, const int32_t* actions, float* rewards, int B, int S, bl_stream_t stream) {
-    if (!board || !seats || !actions || !rewards || B <= 0 || S <= 0 || ((uintptr_t)board & 15) != 0) return BL_EINVAL;
-    if (S > 16) return BL_ETOOBIG;
-    hex_tile_launch(board, board, seats, actions, 0, nullptr, rewards, nullptr, B, S, 0, (hipStream_t)stream);
-    return check_launch();
-}
-
-int bl_hex_step(uint8_t* board, const int32_t* seats, const int32_t* actions, float* rewards, int B, int S, bl_stream_t stream) {
-    if (!board || !seats || !actions || !rewards || B <= 0 || S <= 0) return BL_EINVAL;
-    if (S > 32) return BL_ETOOBIG;
-    if (B >= BL_HEX_TILE_MIN_ENVS && S <= 16 && ((uintptr_t)board & 15) == 0) return bl_hex_step_tiled(board, seats, actions, rewards, B, S, stream);
-    constexpr int G = 16;
-    const int blocks = (B + 64 / G - 1) / (64 / G);
-    hipLaunchKernelGGL((hex_step_kernel<G>), dim3(blocks), dim3(64), (size_t)((S * S + 15) & ~15) * (64 / G),
-                       (hipStream_t)stream, board, seats, actions, rewards, B, S);
-    return check_launch();
-}
-
-int bl_hex_world_step_tiled(const uint8_t* board_in, const int32_t* seats_in, const void* actions, int actions_i64,
-                            uint8_t* board_out, int32_t* seats_out, float* rewards, uint8_t* terminal, int B, int S, bl_stream_t stream) {
-    if (!board_in || !seats_in || !actions || !board_out || !seats_out || !rewards || !terminal || B <= 0 || S <= 0 ||
-        (((uintptr_t)board_in | (uintptr_t)board_out) & 15) != 0) return BL_EINVAL;
-    if (S > 16) return BL_ETOOBIG;
-    hex_tile_launch(board_in, board_out, seats_in, actions, actions_i64, seats_out, rewards, terminal, B, S, 1, (hipStream_t)stream);
-    return check_launch();
-}
-
-int bl_hex_world_step(const uint8_t* board_in, const int32_t* seats_in, const void* actions, int actions_i64,
-                      uint8_t* board_out, int32_t* seats_out, float* rewards, uint8_t* terminal, int B, int S,
-                      bl_stream_t stream) {
-    if (!board_in || !seats_in || !actions || !board_out || !seats_out || !rewards || !terminal || B <= 0 || S <= 0) return BL_EINVAL;
-    if (S > 32) return BL_ETOOBIG;
-    if (B >= BL_HEX_TILE_MIN_ENVS && S <= 16 && (((uintptr_t)board_in | (uintptr_t)board_out) & 15) == 0)
-        return bl_hex_world_step_tiled(board_in, seats_in, actions, actions_i64, board_out, seats_out, rewards, terminal, B, S, stream);
-    const int A = S * S, G = pick_group(B, A);
-    const int blocks = (B + 64 / G - 1) / (64 / G);
-    const size_t lds = (size_t)((A + 15) & ~15) * (64 / G);
-#define CALL(g) hipLaunchKernelGGL((hex_world_step_kernel<g>), dim3(blocks), dim3(64), lds, (hipStream_t)stream, board_in, seats_in, \
-                                   actions, actions_i64, board_out, seats_out, rewards, terminal, B, S)
-    switch (G) { case 8: CALL(8); break; case 16: CALL(16); break; case 32: CALL(32); break; default: CALL(64); break; }
-#undef CALL
-    return check_launch();
-}
-
-/* valid may be null (observe only).  Boards up to 16x16 (64 boards of a workgroup within the default 64 KiB of LDS). */
-int bl_hex_observe_valid_tiled(const uint8_t* board, const int32_t* seats, float* obs, uint8_t* valid, int B, int S, bl_stream_t stream) {
-    if (!board || !seats || !obs || B <= 0 || S <= 0 || (((uintptr_t)board | (uintptr_t)obs | (uintptr_t)valid) & 15) != 0) return BL_EINVAL;
-    if (S > 16) return BL_ETOOBIG;
-    hipLaunchKernelGGL(hex_observe_tile_kernel, dim3((unsigned)((B + 63) / 64)), dim3(256), (size_t)((64 * S * S + 15) & ~15) + 64, (hipStream_t)stream,
-                       board, seats, obs, valid, B, S);
-    return check_launch();
-}
-
-int bl_hex_observe(const uint8_t* board, const int32_t* seats, float* obs, int B, int S, bl_stream_t stream) {
-    if (!board || !seats || !obs || B <= 0 || S <= 0) return BL_EINVAL;
-    if (S > 32) return BL_ETOOBIG;
-    if (B >= BL_HEX_OBSERVE_TILE_MIN_ENVS && S <= 16 && (((uintptr_t)board | (uintptr_t)obs) & 15) == 0)
-        return bl_hex_observe_valid_tiled(board, seats, obs, nullptr, B, S, stream);
-    const long cells = (long)B * S * S;
-    long blocks = (cells + 255) / 256; if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(hex_observe_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, board, seats,
-                       (float2*)obs, cells, S);
-    return check_launch();
-}
-
-int bl_hex_observe_valid(const uint8_t* board, const int32_t* seats, float* obs, uint8_t* valid, int B, int S, bl_stream_t stream) {
-    if (!board || !seats || !obs || !valid || B <= 0 || S <= 0) return BL_EINVAL;
-    if (S > 32) return BL_ETOOBIG;
-    if (B >= BL_HEX_OBSERVE_TILE_MIN_ENVS && S <= 16 && (((uintptr_t)board | (uintptr_t)obs | (uintptr_t)valid) & 15) == 0)
-        return bl_hex_observe_valid_tiled(board, seats, obs, valid, B, S, stream);
-    const long cells = (long)B * S * S;
-    long blocks = (cells + 255) / 256; if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(hex_observe_valid_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, board, seats,
-                       (float2*)obs, valid, cells, S);
     return check_launch();
 }
 
@@ -1998,20 +1365,6 @@ int bl_sim_compact(const bl_search_t* s, const int16_t* leaves, bl_stream_t stre
     return check_launch();
 }
 
-int bl_powf2(const float* x, float* out, long n, bl_stream_t stream) {
-    if (!x || !out || n <= 0) return BL_EINVAL;
-    hipLaunchKernelGGL(powf2_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, out, n);
-    return check_launch();
-}
-
-int bl_selftest(bl_stream_t stream) {
-    const int wrong_safe = bl_fold_selftest(0, (hipStream_t)stream);
-    if (wrong_safe != 0) return wrong_safe < 0 ? wrong_safe : BL_ELAUNCH;      // the ISA-compliant fold must be exact
-    const int wrong_fast = bl_fold_selftest(1, (hipStream_t)stream);
-    if (wrong_fast < 0) return wrong_fast;
-    return wrong_fast;
-}
-
 static int sim_finish_impl(int f32, const bl_search_t* s, int sim, const int16_t* leaves, const void* policy_raw, const void* value_raw,
                            const uint8_t* valid, const int32_t* leaf_seats, bl_stream_t stream) {
     int rc = search_check(s);
@@ -2054,24 +1407,6 @@ int bl_sim_finish_f32(const bl_search_t* s, int sim, const int16_t* leaves, cons
     return sim_finish_impl(1, s, sim, leaves, policy_raw, value_raw, valid, leaf_seats, stream);
 }
 
-int bl_rezero_relu_f16(const void* x, const void* y, const float* alpha, void* x_out, void* relu_out, long n,
-                       bl_stream_t stream) {
-    if (!x || !y || !alpha || !x_out || !relu_out || n <= 0) return BL_EINVAL;
-    const long n8 = n / 8;
-    long blocks = (n8 + 255) / 256; if (blocks > 2048) blocks = 2048; if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(rezero_relu_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)x,
-                       (const uint16_t*)y, alpha, (uint16_t*)x_out, (uint16_t*)relu_out, n8, n);
-    return check_launch();
-}
-
-int bl_rezero_relu_f32(const float* x, const float* y, const float* alpha, float* x_out, float* relu_out, long n,
-                       bl_stream_t stream) {
-    if (!x || !y || !alpha || !x_out || !relu_out || n <= 0) return BL_EINVAL;
-    long blocks = (n + 255) / 256; if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(rezero_relu_f32_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, y, alpha, x_out, relu_out, n);
-    return check_launch();
-}
-
 static int plant_root_impl(const bl_search_t* s, const float* policy_raw, const float* value_raw, const uint8_t* valid,
                            const int32_t* seats, const float* draw, float eps, int gamma, bl_stream_t stream) {
     int rc = search_check(s);
@@ -2111,41 +1446,6 @@ int bl_sim_root(const bl_search_t* s, int sim, void* probs, const void* log_tabl
                                       (hipStream_t)stream, m, (uint16_t*)probs, (const uint16_t*)log_table, (uint16_t*)logits)
     BL_DISPATCH_GK(G, K, CALL)
 #undef CALL
-    return check_launch();
-}
-
-int bl_draw_actions(const void* probs, const float* uniforms, long long* actions, int B, int A, bl_stream_t stream) {
-    if (!probs || !uniforms || !actions || B <= 0 || A <= 0) return BL_EINVAL;
-    hipLaunchKernelGGL(draw_actions_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, (const uint16_t*)probs, uniforms, actions, A);
-    return check_launch();
-}
-
-int bl_categorical(const void* logits, const float* q, long long* actions, int B, int A, bl_stream_t stream) {
-    if (!logits || !q || !actions || B <= 0 || A <= 0) return BL_EINVAL;
-    if (A >= 128) return BL_ETOOBIG;           // torch's sum takes its vectorised path there (row-alignment-dependent order): the caller keeps torch's launches
-    int np2 = 1; while (np2 < A) np2 *= 2;
-    const int W = np2 < 64 ? np2 : 64, iters = np2 / W;
-    const int Wr = last_pow2_le(A) < 64 ? last_pow2_le(A) : 64;
-    hipLaunchKernelGGL(categorical_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, (const uint16_t*)logits, q, actions, A, W, iters, Wr);
-    return check_launch();
-}
-
-int bl_copy_many(const bl_copy_t* items, int n, bl_stream_t stream) {
-    if (n < 0 || n > BL_COPY_MAX || (n > 0 && !items)) return BL_EINVAL;
-    CopyBatch c{};
-    unsigned long long most = 0;
-    for (int k = 0; k < n; k++) {
-        const unsigned long long bytes = items[k].row_bytes * items[k].rows;
-        if (bytes && (!items[k].src || !items[k].dst)) return BL_EINVAL;
-        if (items[k].rows > 1 && (items[k].src_pitch < items[k].row_bytes || items[k].dst_pitch < items[k].row_bytes)) return BL_EINVAL;
-        c.it[k] = items[k];
-        if (bytes > most) most = bytes;
-    }
-    if (most == 0) return BL_OK;
-    unsigned long long blocks = (most / 16 + 255) / 256;           // one 16-byte word per thread of the largest copy ...
-    if (blocks < 1) blocks = 1;
-    if (blocks > 128) blocks = 128;                                 // ... up to 128 blocks per copy, then strided
-    hipLaunchKernelGGL(copy_many_kernel, dim3((unsigned)blocks, n), dim3(256), 0, (hipStream_t)stream, c);
     return check_launch();
 }
 
