@@ -276,11 +276,50 @@ class Learner:
             self.steps += 1
 
 
+def arena_pairs(sizes, width, depth, nodes, eager, rank):
+    """Two search agents per board size (seeds 10 rank, 10 rank + 1), as config 5 plays them."""
+    from boardlaw_amd import networks
+    from boardlaw_amd.hex import Hex
+    from boardlaw_amd.mcts import MCTSAgent, MoveRng
+    pairs = {}
+    for S in sizes:
+        pair = {}
+        for i, name in enumerate(('one', 'two')):
+            torch.manual_seed(10 * rank + i)
+            w0 = Hex.initial(1, S)
+            pair[name] = MCTSAgent(networks.Inference(networks.FCModel(w0.obs_space, w0.action_space, width, depth).cuda(), fused=True),
+                                   graph=not eager, n_nodes=nodes, rng=MoveRng())
+        pairs[S] = pair
+    return pairs
+
+
+class ArenaPlayer:
+    """What one worker process of config 5's match pool holds (arena.MatchPool builds it IN the worker): the agent pairs of the board
+    sizes it is given, created on first use; player(S) plays one match of B games on an S x S board and returns its tallies."""
+
+    def __init__(self, B, width, depth, nodes, eager, rank):
+        sys.path.insert(0, ROOT)
+        self.args, self.pairs = (B, width, depth, nodes, eager, rank), {}
+
+    def __call__(self, S):
+        from boardlaw_amd import arena
+        from boardlaw_amd.hex import Hex
+        B, width, depth, nodes, eager, rank = self.args
+        if S not in self.pairs:
+            self.pairs.update(arena_pairs([S], width, depth, nodes, eager, rank))
+        res = arena.evaluate(Hex.initial(B, S), self.pairs[S])
+        torch.cuda.synchronize()
+        return {'S': S, 'moves': float(sum(r.moves for r in res)), 'games': float(sum(r.games for r in res)), 'wins': [[float(x) for x in r.wins] for r in res]}
+
+
 def arena_config(args):
     """--config 5: the arena sweep on this GPU -- for every board size 3..11 one match of 2048 games between two 64-sim 512x4 search
     agents through arena.evaluate (seat-permuted, masked calls of a new batch size every round, argmax actions; captured moves per
-    capacity bucket).  A step is one sweep over the nine sizes; sims = env-moves x 64.  Prints the one-line JSON."""
-    from boardlaw_amd import _native, arena, networks, parallel
+    capacity bucket).  A step is one sweep over the nine sizes; sims = env-moves x 64.  Since round 6 the nine matches are played by
+    arena.workers_per_gpu(envs) + 1 = 4 persistent worker processes per GPU, board sizes dealt largest first (arena.MatchPool,
+    arena.lpt_partition): a match of 2048 games leaves most of the chip idle, three side by side do not (--arena-workers 0: the
+    round-5 form, one match at a time in this process).  Prints the one-line JSON."""
+    from boardlaw_amd import _native, arena, parallel
     from boardlaw_amd.hex import Hex
     from boardlaw_amd.mcts import MCTSAgent, MoveRng
     rank, world, local = parallel.env_rank()
@@ -289,17 +328,22 @@ def arena_config(args):
     parallel.init(os.environ.get('BENCH_BACKEND', 'nccl'))
     lib = _native.lib()
     sizes, B, T = list(range(3, 12)), args.envs if args.envs != ENVS else 2048, args.nodes
-    pairs = {}
-    for S in sizes:
-        pair = {}
-        for i, name in enumerate(('one', 'two')):
-            torch.manual_seed(10 * rank + i)
-            w0 = Hex.initial(1, S)
-            pair[name] = MCTSAgent(networks.Inference(networks.FCModel(w0.obs_space, w0.action_space, args.width, args.depth).cuda(), fused=True),
-                                   graph=not args.eager, n_nodes=T, rng=MoveRng())
-        pairs[S] = pair
+    # workers_per_gpu (3 at 2048 games) is the optimum for EQUAL matches side by side; a sweep's matches are unequal (11x11 takes 18 x
+    # as long as 3x3), and one more worker lets the longest match run alone: 19.0 / 33.4 / 46.8 / 55.6 M sims/s at 0 / 2 / 3 / 4
+    # workers (profiles/r06_config5_workers.txt)
+    W = arena.workers_per_gpu(B) + 1 if args.arena_workers is None else args.arena_workers
+    pool, parts = None, None
+    if W > 0:
+        parts = [[sizes[i] for i in part] for part in arena.lpt_partition([S ** 2.2 for S in sizes], W)]      # a match's time grows like S^2.2 (profiles/r03_arena_sweep.txt)
+        pool = arena.MatchPool(ArenaPlayer, (B, args.width, args.depth, T, args.eager, rank), n_workers=W, device=local)
+        pairs = arena_pairs([9], args.width, args.depth, T, args.eager, rank)        # the roofline probe below runs in this process
+    else:
+        pairs = arena_pairs(sizes, args.width, args.depth, T, args.eager, rank)
 
     def sweep():
+        if pool is not None:
+            done = [r for rs in pool.play(parts) for r in rs]
+            return sum(r['moves'] for r in done), sum(r['games'] for r in done)
         moves = games = 0
         for S in sizes:
             res = arena.evaluate(Hex.initial(B, S), pairs[S])
@@ -318,6 +362,8 @@ def arena_config(args):
     elapsed = parallel.max_over_ranks(elapsed)
     moves_all, games_all = parallel.sum_over_ranks(moves), parallel.sum_over_ranks(games)
     value = moves_all * T / elapsed
+    if pool is not None:
+        pool.close()
     if rank != 0:
         if world > 1:
             torch.distributed.destroy_process_group()
@@ -351,8 +397,9 @@ def arena_config(args):
            'config': {'workload': f'BASELINE config 5: arena sweep, boards 3..11, {B} games per board size between two {T}-sim FCModel {args.width}x{args.depth} search agents '
                                   '(arena.evaluate: seat-permuted, masked variable-size calls, argmax actions); step = one sweep over the nine sizes; sims = env-moves x sims/move',
                       'boards': sizes, 'envs_per_board': B, 'nodes': T, 'launch': 'eager' if args.eager else 'hip-graph per move and capacity bucket',
+                      'matches_in_flight_per_gpu': max(W, 1), 'boards_per_worker': parts,
                       'games_per_sec': games_all / elapsed, 'env_moves_per_step': moves_all / args.steps,
-                      'parallelism': f'replicas x{world} (every rank plays its own sweep; tools/arena_sweep.py fans the board sizes out over a worker pool instead)'},
+                      'parallelism': f'replicas x{world} (every rank plays its own sweep' + (f' on {W} persistent worker processes on its GPU, board sizes dealt largest first' if W > 0 else '') + ')'},
            'roofline': {'bound': 'hbm', 'kernel': 'bl::sim_expand2_kernel (bl_sim_expand)', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                         'frac': achieved / HBM_PEAK_GBS, 'traffic': None, 'kernel_us': float(us.mean()), 'launches_timed': int(len(us)),
                         'bytes_per_env_per_launch': per_env, 'mean_envs_per_launch': float(np.mean(live[:len(us)])),
@@ -441,6 +488,7 @@ def main():
     ap.add_argument('--no-learner', action='store_true', help='--config 4 without the learner step (self-play only)')
     ap.add_argument('--buffer', type=int, default=64, help='--config 4: moves in the learner\'s buffer (boardlaw/main.py:150 keeps 64)')
     ap.add_argument('--eager', action='store_true', help='launch kernel by kernel instead of replaying a HIP graph per move')
+    ap.add_argument('--arena-workers', type=int, default=None, help='--config 5: worker processes per GPU (default: arena.workers_per_gpu(envs) + 1 = 4 for 2048 games per match; 0 = one match at a time in this process)')
     args = ap.parse_args()
     respawn_per_gpu(args)
     shapes = {1: (5, 64, 16, 16, 4), 4: (13, 1024, 256, 1024, 8)}      # (board, envs per GPU, sims/move, width, depth) -- BASELINE.json configs

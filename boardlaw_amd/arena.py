@@ -252,13 +252,31 @@ def _pool_worker(index, n_devices, inbox, outbox):
             outbox.put((key, None, f'{type(e).__name__}: {e}\n{traceback.format_exc()}'))
 
 
-def run_jobs(jobs, n_workers=None, context='spawn', poll_seconds=2.0):
-    """jobs: {key: (picklable function, args)} -> yields (key, result) as they finish, from a pool of n_workers processes, one
-    per GPU by default (worker n on GPU n % n_gpus).  n_workers == 0: everything in this process, in order (the reference's
-    serial executor, rebar/parallel.py:15-27)."""
+def workers_per_gpu(n_envs):
+    """How many matches to keep in flight on one GPU.  A match of up to 2048 envs leaves the chip mostly idle (both search kernels
+    are bound by the latency of one env's chain): independent matches side by side, one PROCESS each (their
+    own streams, generators and captured moves), reach 18 -> 34 -> 43 M sims/s at 1 / 2 / 3 per MI355X and fall back at 4
+    (profiles/r03_arena_sweep.txt); from 4096 envs a second one still adds half, beyond that one fills the chip."""
+    return 3 if n_envs <= 2048 else (2 if n_envs <= 4096 else 1)
+
+
+def lpt_partition(costs, n):
+    """Longest-processing-time-first: indices of `costs` dealt, largest first, to whichever of n bins is lightest -- the board sizes
+    of a sweep over the workers of a pool.  Returns n lists of indices (each in dealing order: its largest job first)."""
+    bins, loads = [[] for _ in range(n)], [0.] * n
+    for i in sorted(range(len(costs)), key=lambda i: -costs[i]):
+        k = loads.index(min(loads))
+        bins[k].append(i); loads[k] += costs[i]
+    return bins
+
+
+def run_jobs(jobs, n_workers=None, context='spawn', poll_seconds=2.0, per_device=1):
+    """jobs: {key: (picklable function, args)} -> yields (key, result) as they finish, from a pool of n_workers processes, by
+    default `per_device` per GPU (worker n on GPU n % n_gpus; evaluate_gen passes workers_per_gpu(n_envs_per)).  n_workers == 0:
+    everything in this process, in order (the reference's serial executor, rebar/parallel.py:15-27)."""
     n_devices = torch.cuda.device_count() if torch.cuda.is_available() else 0
     if n_workers is None:
-        n_workers = max(n_devices, 1)
+        n_workers = max(n_devices, 1) * max(int(per_device), 1)
     if n_workers == 0:
         for key, (fn, args) in jobs.items():
             yield key, fn(*args)
@@ -301,19 +319,106 @@ def evaluate_gen(worldfunc, agentfunc, games, names=None, n_envs_per=512, chunks
     """neural.py:202-274: plays every missing game of an all-vs-all `games` matrix ((n,n) games played per ordered pair; a pandas
     DataFrame indexed by name, or an array with `names`), block by block, on a pool of worker processes (one per GPU by default).
     Yields (list of result records of one finished block, running totals) as blocks finish.  worldfunc(n_envs) and
-    agentfunc(name) must be picklable (module-level functions); they run in the workers."""
+    agentfunc(name) must be picklable (module-level functions); they run in the workers.  n_workers None: workers_per_gpu(n_envs_per)
+    processes per GPU -- blocks of up to 2048 games run three side by side on a GPU."""
     if hasattr(games, 'index'):
         assert list(games.index) == list(games.columns)
         names, games = list(games.index), games.values
     jobs = {k: (_chunk_job, (worldfunc, agentfunc, block_names, played, n_envs_per)) for k, (block_names, played) in chunk_jobs(games, names, n_envs_per, chunks).items()}
     stats = arrdict.dotdict(finished=0, total=len(jobs), moves=0., games=0., matchups=0, start=time.time())
-    for key, records in run_jobs(jobs, n_workers, context):
+    for key, records in run_jobs(jobs, n_workers, context, per_device=workers_per_gpu(n_envs_per)):
         results = [arrdict.dotdict(r) for r in records]
         stats['finished'] += 1
         stats['end'] = time.time()
         for r in results:
             stats['moves'] += r.moves; stats['games'] += r.games; stats['matchups'] += 1
         yield results, arrdict.dotdict(stats)
+
+
+def _match_pool_worker(index, device, factory, factory_args, inbox, outbox):
+    try:
+        if device is not None and torch.cuda.is_available():
+            torch.cuda.set_device(device)
+        player = factory(*factory_args)
+        outbox.put((index, 'ready', None))
+    except BaseException as e:
+        import traceback
+        outbox.put((index, None, f'{type(e).__name__}: {e}\n{traceback.format_exc()}'))
+        return
+    while True:
+        jobs = inbox.get()
+        if jobs is None:
+            return
+        try:
+            with torch.no_grad():
+                outbox.put((index, [player(j) for j in jobs], None))
+        except BaseException as e:
+            import traceback
+            outbox.put((index, None, f'{type(e).__name__}: {e}\n{traceback.format_exc()}'))
+
+
+class MatchPool:
+    """n_workers PERSISTENT worker processes on one device, each holding its own `player = factory(*factory_args)` -- its agents and
+    the moves it has captured stay alive between calls, so a sweep that is played again and again (bench.py --config 5) pays process
+    start-up and capture once.  play(assignments): assignments[k] = list of jobs for worker k (played in that order, player(job));
+    returns the list of result lists.  The matches of different workers overlap on the GPU; nothing is exchanged between them."""
+
+    def __init__(self, factory, factory_args=(), n_workers=1, device=None, context='spawn', start_timeout=600.):
+        import torch.multiprocessing as mp
+        ctx = mp.get_context(context)
+        self.outbox = ctx.Queue()
+        self.inboxes = [ctx.Queue() for _ in range(n_workers)]
+        self.procs = [ctx.Process(target=_match_pool_worker, args=(i, device, factory, factory_args, self.inboxes[i], self.outbox), daemon=True)
+                      for i in range(n_workers)]
+        for p in self.procs:
+            p.start()
+        for _ in self.procs:
+            self._get(start_timeout)
+
+    def _get(self, timeout):
+        import queue
+        waited = 0.
+        while True:
+            try:
+                index, result, err = self.outbox.get(timeout=2.0)
+            except queue.Empty:
+                waited += 2.0
+                dead = [(i, p.exitcode) for i, p in enumerate(self.procs) if not p.is_alive()]
+                if dead or waited > timeout:
+                    self.close()
+                    raise RuntimeError(f'arena match pool: worker(s) died or timed out: (worker, exit code) {dead}')
+                continue
+            if err is not None:
+                self.close()
+                raise RuntimeError(f'arena match pool: worker {index} failed:\n{err}')
+            return index, result
+
+    def play(self, assignments, timeout=3600.):
+        assert len(assignments) == len(self.procs)
+        for inbox, jobs in zip(self.inboxes, assignments):
+            inbox.put(list(jobs))
+        results = [None] * len(self.procs)
+        for _ in self.procs:
+            index, result = self._get(timeout)
+            results[index] = result
+        return results
+
+    def close(self):
+        for inbox in self.inboxes:
+            try:
+                inbox.put(None)
+            except Exception:
+                pass
+        for p in self.procs:
+            p.join(timeout=10)
+            if p.is_alive():
+                p.terminate()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
 
 
 from .analysis import rollout  # noqa: E402,F401  (kept here for callers that imported it from arena)

@@ -38,3 +38,14 @@ def die(code):
 def device_of_worker(_):
     import torch
     return torch.cuda.current_device() if torch.cuda.is_available() else -1
+
+
+class Accumulator:
+    """A MatchPool player that remembers what it has been asked before: persistent workers keep their state between plays."""
+
+    def __init__(self, offset):
+        self.offset, self.seen = offset, []
+
+    def __call__(self, job):
+        self.seen.append(job)
+        return (os.getpid(), job * job + self.offset, len(self.seen))

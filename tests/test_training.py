@@ -490,6 +490,34 @@ def test_run_jobs_pool_and_serial():
         os.environ['PYTHONPATH'] = env
 
 
+def test_match_pool_keeps_its_workers_and_lpt_partition():
+    """arena.MatchPool (bench.py --config 5: several matches in flight per GPU): persistent workers -- the same processes and
+    their players' state across plays --, results per worker in order; arena.lpt_partition deals the largest jobs first to the
+    lightest worker; arena.workers_per_gpu is 3 for matches of up to 2048 games."""
+    from boardlaw_amd import arena
+    import pool_helpers
+    assert [arena.workers_per_gpu(n) for n in (64, 2048, 2049, 4096, 8192)] == [3, 3, 2, 2, 1]
+    sizes = list(range(3, 12))
+    parts = arena.lpt_partition([S ** 2.2 for S in sizes], 3)
+    assert sorted(i for p_ in parts for i in p_) == list(range(9)) and [p_[0] for p_ in parts] == [8, 7, 6]
+    loads = [sum(sizes[i] ** 2.2 for i in p_) for p_ in parts]
+    assert max(loads) / min(loads) < 1.25
+    env = os.environ.get('PYTHONPATH', '')
+    os.environ['PYTHONPATH'] = os.pathsep.join([os.path.dirname(os.path.abspath(__file__)), env])
+    try:
+        with arena.MatchPool(pool_helpers.Accumulator, (100,), n_workers=2, device=None) as pool:
+            a = pool.play([[1, 2, 3], [4]])
+            b = pool.play([[5], [6, 7]])
+        assert [[r[1] for r in rs] for rs in a] == [[101, 104, 109], [116]] and [[r[1] for r in rs] for rs in b] == [[125], [136, 149]]
+        assert a[0][0][0] == b[0][0][0] and a[1][0][0] == b[1][0][0] and a[0][0][0] != a[1][0][0]        # the same two processes
+        assert [r[2] for r in b[0]] == [4] and [r[2] for r in b[1]] == [2, 3]                            # which remember their earlier jobs
+        with pytest.raises(RuntimeError, match='failed'):
+            with arena.MatchPool(pool_helpers.Accumulator, (0,), n_workers=1, device=None) as pool:
+                pool.play([['x']])
+    finally:
+        os.environ['PYTHONPATH'] = env
+
+
 def test_evaluate_gen_two_workers_equals_one_chunk_evaluator(oracle):
     """The fan-out (two worker processes, blocks of two agents) plays exactly the games a single ChunkEvaluator over all four
     agents plays: same wins and moves per ordered pair (deterministic agents; each pair's games do not depend on the others)."""

@@ -1,8 +1,8 @@
 """BASELINE config 5 -- the mixed board-size arena sweep (boards 3..11, 2048 games each between two 64-sim search agents,
 arena.evaluate's masked calls) -- fanned out like the reference fans out its evaluation (boardlaw/arena/neural.py:257-274 over
 rebar/parallel.py:28-57): one job per board size (x --repeat), a pool of worker processes, worker n on GPU n % n_gpus.
-`--workers` defaults to one per GPU; more than one per GPU runs independent matches side by side on a GPU (the search kernels
-are latency-bound, so a second resident match fills cycles the first leaves idle -- DESIGN.md section 5).
+`--workers` defaults to arena.workers_per_gpu(envs) per GPU -- three for matches of up to 2048 games: independent matches side by
+side on a GPU (the search kernels are latency-bound, so further resident matches fill cycles the first leaves idle -- DESIGN.md 5).
 
     python tools/arena_sweep.py [--gpus N] [--workers W] [--boards 3,5,7,9,11] [--envs 2048] [--repeat 1] [--eager]
 
@@ -56,7 +56,7 @@ def dry_match(S, n_envs, *_):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=None, help='GPUs to use (default: all visible)')
-    ap.add_argument('--workers', type=int, default=None, help='worker processes (default: one per GPU)')
+    ap.add_argument('--workers', type=int, default=None, help='worker processes (default: arena.workers_per_gpu(envs) per GPU: three for matches of up to 2048 games)')
     ap.add_argument('--boards', type=str, default='3,5,7,9,11')
     ap.add_argument('--envs', type=int, default=2048)
     ap.add_argument('--nodes', type=int, default=64)
@@ -73,7 +73,7 @@ def main():
     if args.gpus is not None and not dry:
         os.environ['HIP_VISIBLE_DEVICES'] = ','.join(str(i) for i in range(args.gpus))
     n_gpus = 0 if dry else torch.cuda.device_count()
-    workers = args.workers if args.workers is not None else max(n_gpus, 1)
+    workers = args.workers if args.workers is not None else max(n_gpus, 1) * arena.workers_per_gpu(args.envs)
     boards = [int(x) for x in args.boards.split(',')]
     fn = dry_match if dry else search_match
     start_at = time.time() + args.together if args.together > 0 else None
