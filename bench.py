@@ -183,6 +183,52 @@ def rate_of(agent, worlds, steps, warmup, barrier):
     return worlds.n_envs * agent.kwargs['n_nodes'] * steps / (time.perf_counter() - t)
 
 
+def operating_point(envs, net, lib, steps, warmup, barrier, rank):
+    """The same self-play moves at another batch size -- called with 32768 envs per GPU, the reference's own actor shape
+    (boardlaw/main.py:147: `n_envs=32*1024`; BASELINE.md: "default actor shape"), where the search kernels are bound by throughput
+    (bl_sim_expand by VALU issue, bl_sim_infer_finish by the L2's bandwidth: DESIGN.md section 5) instead of one env's chain.
+    Returns sims/s of captured moves and bl_sim_expand's own roofline object at that batch (HIP events around every launch of an
+    eager re-run of the moves; d, k counted by the kernel)."""
+    from boardlaw_amd import networks
+    from boardlaw_amd.hex import Hex
+    from boardlaw_amd.mcts import MCTSAgent, MoveRng
+    gen = torch.Generator(device='cuda'); gen.manual_seed(5000 + rank)
+    worlds = premix(Hex.initial(envs, BOARD), BOARD * BOARD // 3, gen)
+    inf = networks.Inference(net, fused=True)
+    agent = MCTSAgent(inf, n_nodes=NODES, graph=True, rng=MoveRng())
+    rate = rate_of(agent, worlds, steps, warmup, barrier)
+    del agent
+    t_exp, t_fin = TimedExpand(lib), TimedExpand(lib, 'bl_sim_infer_finish')
+    lib.bl_sim_expand, lib.bl_sim_infer_finish = t_exp, t_fin
+    try:
+        probe = MCTSAgent(inf, n_nodes=NODES, graph=False, rng=MoveRng())
+        w = probe.play(worlds)[1]
+        t_exp.on = t_fin.on = True
+        for _ in range(2):
+            w = probe.play(w)[1]
+        torch.cuda.synchronize()
+    finally:
+        lib.bl_sim_expand, lib.bl_sim_infer_finish = t_exp.orig, t_fin.orig
+    d, k, its = tree_statistics(worlds, net, NODES)
+    A = BOARD * BOARD
+    per_launch = expand_bytes_per_env(A, 2, d, k) * envs
+    achieved = per_launch / (t_exp.mean_us() * 1e-6) / 1e9
+    whole = total_bytes_per_sim(A, 2, NODES, d, k)
+    del probe, w, worlds
+    torch.cuda.empty_cache()
+    return {'sims_per_sec': rate, 'envs_per_gpu': envs, 'ms_per_step': 1e3 * envs * NODES / rate, 'steps': steps,
+            'bl_sim_expand_us': t_exp.mean_us(), 'bl_sim_infer_finish_us': t_fin.mean_us() if t_fin.pairs else None,
+            'gpu_ns_per_descent': 1e3 * t_exp.mean_us() / envs,
+            'd_policy_evals_per_descent': round(d, 3), 'k_child_lookups_per_descent': round(k, 3),
+            'bytes_per_sim_whole_path': round(whole, 1), 'hbm_frac_whole_path': whole * rate / (HBM_PEAK_GBS * 1e9),
+            'roofline': {'bound': 'hbm', 'kernel': 'bl::sim_expand2_kernel (bl_sim_expand), one wave per env', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                         'frac': achieved / HBM_PEAK_GBS, 'traffic': None, 'kernel_us': t_exp.mean_us(), 'bytes_per_launch': per_launch,
+                         'launches_timed': len(t_exp.pairs),
+                         'binds': 'VALU issue: 101.5 M VALU instructions per launch on 1024 SIMDs = 165 of 186 us (profiles/r06_pmc32k_SQ1.csv); '
+                                  'HBM-side traffic 177 MB per launch (profiles/r06_pmc32k_FETCH_SIZE / WRITE_SIZE.csv) = 0.95 TB/s'},
+            'note': 'NOT the metric (BASELINE config 2 quotes it at 4096 envs): the reference\'s default actor shape, boardlaw/main.py:147'}
+
+
 def hex_kernels(envs=(4096, 1 << 20), steps=1024, boardsize=11):
     """The reference's step / observe micro-benchmarks (boardlaw/hex/tests.py:186-215: 4096 envs x 1024 calls of `cuda.step` on one
     fixed action set resp. `cuda.observe`, after 1024 random moves) for the two board kernels of the path that really are HBM-bound,
@@ -255,7 +301,12 @@ class Learner:
     def __init__(self, net, n_envs, buffer_len, device):
         from boardlaw_amd import parallel
         if not torch.distributed.is_initialized():         # one rank: a one-rank group, so that the collective runs and is timed
-            os.environ.setdefault('MASTER_ADDR', '127.0.0.1'); os.environ.setdefault('MASTER_PORT', '29535')
+            os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+            if 'MASTER_PORT' not in os.environ:             # a free port: two bench runs on one host must not meet at a fixed one
+                import socket
+                with socket.socket() as sock:
+                    sock.bind(('127.0.0.1', 0))
+                    os.environ['MASTER_PORT'] = str(sock.getsockname()[1])
             backend = os.environ.get('BENCH_BACKEND', 'nccl')
             kw = {'device_id': device} if backend == 'nccl' else {}
             torch.distributed.init_process_group(backend, rank=0, world_size=1, **kw)
@@ -485,6 +536,7 @@ def main():
     ap.add_argument('--no-soak', action='store_true', help='skip the 200 extra moves behind value_after_self_play_drift')
     ap.add_argument('--no-variants', action='store_true', help='skip the torch-GEMM and fp32-leaves timed regions (value_torch_gemms, value_fp32_leaves)')
     ap.add_argument('--no-hex-kernels', action='store_true', help='skip the step / observe micro-benchmark (hex_kernels)')
+    ap.add_argument('--no-32k', action='store_true', help='skip the region at 32768 envs per GPU (value_32k_envs)')
     ap.add_argument('--no-learner', action='store_true', help='--config 4 without the learner step (self-play only)')
     ap.add_argument('--buffer', type=int, default=64, help='--config 4: moves in the learner\'s buffer (boardlaw/main.py:150 keeps 64)')
     ap.add_argument('--eager', action='store_true', help='launch kernel by kernel instead of replaying a HIP graph per move')
@@ -693,6 +745,10 @@ def main():
             torch.cuda.current_stream().wait_stream(s_)
         del actors, pair
 
+    value_32k = None
+    if world == 1 and not args.eager and default_shape and args.envs == ENVS and not args.no_32k and not args.plain_network and not args.torch_gemms:
+        value_32k = operating_point(32768, net, lib, max(args.steps // 2, 5), args.warmup, barrier, rank)
+
     drifted = None
     if world == 1 and not args.eager and default_shape and not args.no_soak:
         # the timed region above starts from freshly pre-mixed boards; self-play drifts to its own mix of positions (shorter games
@@ -791,6 +847,7 @@ def main():
                        'value_reference_rng_protocol': value,          # the headline IS on the reference's stream (MoveRng above)
                        'value_rand_like_call_by_call': value_torch_rng,  # TorchRng: the same stream drawn with T-1 separate launches
                        'value_after_self_play_drift': drifted,
+                       'value_32k_envs': value_32k,        # 32768 envs per GPU (boardlaw/main.py:147), with its own roofline object
                        'search_kernels_only': search_only,
                        'two_actors_per_gpu': two_actors,
                        'network_mfma_bound_sims_per_sec': 2.5e15 / (2 * (2 * A * WIDTH + DEPTH * WIDTH * WIDTH + WIDTH * (A + 1))),

@@ -114,8 +114,8 @@ __device__ __forceinline__ int hex_step_quad(uint8_t* cells, int S, int seat, in
         uint32_t P[NW], M[NW];
 #pragma unroll
         for (int w = 0; w < NW; w++) {
-            // branch-free: all eight reads of a word in flight at once (a read beyond the board -- at most 31 bytes, into the next
-            // env's cells or the pad behind the last one -- is masked out by `a < A`); as `if (...) bits |= ...` the compiler put every
+            // branch-free: all eight reads of a word in flight at once (a read beyond the board -- up to 32 NW - A bytes, into the
+            // following envs' cells or the pad the launcher allocates behind the last one -- is masked out by `a < A`); as `if (...) bits |= ...` the compiler put every
             // cell behind its own EXEC branch with a wait per read: ten instructions and an LDS round trip per cell
             uint32_t bits = 0;
             uint8_t c[8];
@@ -333,7 +333,9 @@ static void hex_tile_launch(const uint8_t* board_in, uint8_t* board_out, const i
         if (a % S < S - 1) hm.not_last[a >> 5] |= 1u << (a & 31);
     }
     const dim3 grid((unsigned)((B + 63) / 64));
-    const size_t lds = (size_t)((64 * A + 15) & ~15) + 32;      // + the scan's over-read behind the last env
+    // + the scan's over-read behind the last env: it reads all 32 NW bytes of an env's words whatever A is (up to 32 NW - A bytes past
+    // the board; round-5 advisor: the old pad of 32 only held because of LDS allocation granularity)
+    const size_t lds = (size_t)((64 * A + 15) & ~15) + (A <= 128 ? 128 : 256);
     if (A <= 128)
         hipLaunchKernelGGL((hex_step_tile_kernel<4>), grid, dim3(256), lds, stream, board_in, board_out, seats_in, actions, actions_i64, seats_out,
                            rewards, terminal, B, S, world, hm);

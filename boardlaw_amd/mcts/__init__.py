@@ -103,6 +103,63 @@ class MoveRng(TorchRng):
     # reproduce; from 128 on it vectorises with an order that depends on each row's address alignment: torch's own launches stay
     FUSED_MAX_ACTIONS = 127
 
+    _layout_checked = {}        # device index -> bool: torch's reduce order on this build is the one the fused draws reproduce
+
+    @classmethod
+    def torch_layout_ok(cls, device):
+        """bl_categorical and bl_sim_plant_root_gamma restate the lane layout and tree order of torch's row reductions `as this torch
+        build on ROCm orders it` (csrc/bl_device.h: torch_row_sum).  A torch upgrade could change that order silently: the draws
+        would stay valid but stop being bit-identical to torch's and the reference's.  So, once per device and process (outside any
+        capture; the generator is put back), the two fused draws are compared with the torch launches they stand for on a small
+        case; on a mismatch the fused routes are switched off for the process (FUSED_MAX_ACTIONS = 0: torch's own launches run)."""
+        device = torch.device(device)
+        index = device.index if device.index is not None else torch.cuda.current_device()
+        if index in cls._layout_checked:
+            return cls._layout_checked[index]
+        if torch.cuda.is_current_stream_capturing():
+            return True                                                   # nothing cached: checked at the next eager use
+        cls._layout_checked[index] = True                                 # (the check below goes through the routes it guards)
+        gen = torch.cuda.default_generators[index]
+        state = gen.get_state()
+        ok = True
+        try:
+            with torch.cuda.device(index):
+                dev = torch.device('cuda', index)
+                for A in (25, 81):
+                    gen.manual_seed(1234 + A)
+                    logits = (torch.randn(64, A, device=dev) * 2).half()            # (device-side draws: the CPU generator is not touched)
+                    logits[torch.rand(64, A, device=dev) < 0.3] = -float('inf')
+                    logits[:, 0] = 0.5
+                    rng = cls()
+                    gen.manual_seed(99); a = rng.categorical_f16(logits); off_a = gen.get_offset()
+                    gen.manual_seed(99); b = rng.categorical(logits.float()); off_b = gen.get_offset()
+                    ok = ok and bool(torch.equal(a, b)) and off_a == off_b
+                # the Dirichlet's normalisation: gamma variates normalised inside the root's launch against torch's finished sample
+                from .. import hex as hexmod
+                world = hexmod.Hex.initial(16, 5, device=dev)
+                rows = []
+                for fused_max in (cls.FUSED_MAX_ACTIONS, 0):
+                    rng = cls(); rng.FUSED_MAX_ACTIONS = fused_max
+                    m = MCTS(world, n_nodes=2, rng=rng)
+                    gen.manual_seed(7)
+                    alpha = torch.full((25,), 0.4, dtype=torch.float, device=dev)
+                    pol, val = torch.linspace(-2, 2, 16 * 25, device=dev).reshape(16, 25).contiguous(), torch.zeros(16, device=dev)
+                    draw = (rng.gamma_variates(alpha, (16,)) if fused_max else rng.dirichlet(alpha, (16,))).float().contiguous()
+                    plant = _native.lib().bl_sim_plant_root_gamma if fused_max else _native.lib().bl_sim_plant_root
+                    _native.check(plant(ctypes.byref(m._search), pol.data_ptr(), val.data_ptr(), world.valid.contiguous().data_ptr(),
+                                        world.seats.int().contiguous().data_ptr(), draw.data_ptr(), 0.25, _native.stream(dev)))
+                    rows.append(m.decisions.logits[:, 0].clone())
+                ok = ok and bool(torch.equal(rows[0].view(torch.int16), rows[1].view(torch.int16)))
+        finally:
+            gen.set_state(state)
+        if not ok:
+            import warnings
+            warnings.warn('boardlaw_amd: this torch build orders its row reductions differently from the layout bl_categorical / '
+                          'bl_sim_plant_root_gamma reproduce; the fused draws are switched off (torch\'s own launches run, same stream)')
+            cls.FUSED_MAX_ACTIONS = 0
+        cls._layout_checked[index] = ok
+        return ok
+
     def gamma_variates(self, alpha, shape):
         """The standard-gamma variates torch's Dirichlet sampler starts from (at::_sample_dirichlet = _standard_gamma, then sum and
         clamped quotient): the same kernel, the same use of the generator; bl_sim_plant_root_gamma does the rest inside the root's
@@ -113,7 +170,8 @@ class MoveRng(TorchRng):
         """categorical(logits.float()) for (B,A) f16 device logits: torch's own exponential_ draw, then bl_categorical -- the
         normalisation, softmax, quotient and argmax of the launches below as one kernel with torch's rounding points and summation
         orders (tests/test_rng_stream.py::test_fused_draws_equal_torchs).  Same actions, same use of the generator."""
-        if not (logits.is_cuda and logits.dtype == torch.half and logits.ndim == 2 and logits.shape[-1] <= self.FUSED_MAX_ACTIONS):
+        if not (logits.is_cuda and logits.dtype == torch.half and logits.ndim == 2 and logits.shape[-1] <= self.FUSED_MAX_ACTIONS
+                and (self.FUSED_MAX_ACTIONS == 0 or self.torch_layout_ok(logits.device))):
             return self.categorical(logits.float())
         B, A = logits.shape
         q = torch.empty((B, A), dtype=torch.float, device=logits.device).exponential_(1, generator=self.generator)
@@ -289,7 +347,9 @@ class MCTS:
             plant = _native.lib().bl_sim_plant_root
             if hasattr(self.rng, 'gamma'):
                 draw = self.rng.gamma(alpha, (self.n_envs,)).float().contiguous()      # FastRng: not the reference's normalisation
-            elif hasattr(self.rng, 'gamma_variates') and self.n_actions <= getattr(self.rng, 'FUSED_MAX_ACTIONS', 0):
+            elif (hasattr(self.rng, 'gamma_variates') and self.n_actions <= getattr(self.rng, 'FUSED_MAX_ACTIONS', 0)
+                  and (not hasattr(self.rng, 'torch_layout_ok') or self.rng.torch_layout_ok(self.device))
+                  and self.n_actions <= getattr(self.rng, 'FUSED_MAX_ACTIONS', 0)):
                 # the reference's draw (mcts/__init__.py:16-18) with its normalisation inside the root's launch: same bits
                 draw = self.rng.gamma_variates(alpha, (self.n_envs,)).float().contiguous()
                 plant = _native.lib().bl_sim_plant_root_gamma

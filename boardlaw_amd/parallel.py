@@ -197,7 +197,7 @@ class GradientBucket:
             del self.events[:-self.MAX_EVENTS]
 
     def collective_ms(self):
-        """Device time of every timed all-reduce + scaling so far (synchronises)."""
+        """Device time of the timed all-reduces + scalings still on record -- the last MAX_EVENTS of them (synchronises)."""
         if not self.events:
             return []
         torch.cuda.synchronize()
