@@ -853,6 +853,10 @@ def main():
                        'network_mfma_bound_sims_per_sec': 2.5e15 / (2 * (2 * A * WIDTH + DEPTH * WIDTH * WIDTH + WIDTH * (A + 1))),
                        'd_policy_evals_per_descent': round(d, 3), 'k_child_lookups_per_descent': round(k, 3),
                        'newton_iters_per_eval': round(its, 3),
+                       # the reference's own unit for its descent benchmark (boardlaw/mcts/tests.py:163-182: ns/descent of cuda.descend): one
+                       # descent per env per bl_sim_expand launch -- the launch also expands, steps and observes the leaf, so an upper bound;
+                       # beside cpu_baseline.ns_per_descent_*
+                       'gpu_ns_per_descent': 1e3 * kernel_us / args.envs,
                        'bytes_per_sim_whole_path': round(total_bytes_per_sim(A, S, NODES, d, k), 1),
                        'hbm_frac_whole_path': total_bytes_per_sim(A, S, NODES, d, k) * value / world / (HBM_PEAK_GBS * 1e9)},
             'roofline': {'bound': 'hbm', 'kernel': 'bl::sim_expand2_kernel (bl_sim_expand)', 'achieved': achieved, 'peak': HBM_PEAK_GBS,

@@ -869,14 +869,15 @@ __device__ __forceinline__ void st_sc1(void* p, uint2 v) {
 
 // One workgroup's share of one Linear: rows 32 * rowtile .., features 128 * colgroup ..  Contains one workgroup barrier; waves
 // without a tile and lanes whose row is beyond M leave after it.
-template <int RD, int KBC, typename PRE>
+// LRG: row groups of 32 rows per workgroup (every weight fragment then feeds LRG MFMAs: see gemm_run).
+template <int RD, int KBC, typename PRE, int LRG = 1>
 __device__ __forceinline__ void layer_body(const LayerArgs& a, const int rowtile, const int colgroup, uint16_t* R, PRE pre) {
     const int ld = a.Kpad + 8;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int row0 = rowtile * 32, tile = colgroup * 4 + wave, ntiles = a.N >> 5;
+    const int row0 = rowtile * 32 * LRG, tile = colgroup * 4 + wave, ntiles = a.N >> 5;
     const int brow = lane & 31, hf = lane >> 5;
     Ring<1, RD> rg;
-    float16v acc[1];
+    float16v acc[LRG];
     const bool active = tile < ntiles;
     // EARLY (the persistent kernel): the first weight fragments are requested BEFORE `pre` waits for the previous layer -- weights
     // do not depend on it -- and the input rows after
@@ -887,32 +888,39 @@ __device__ __forceinline__ void layer_body(const LayerArgs& a, const int rowtile
     if ((a.ldx & 7) == 0 && (a.Kvalid & 7) == 0) {
         // 8 threads per row, 16 bytes each: one 128-byte line per row and step; all of a thread's chunks in flight at once
         // (Kpad <= 1024: at most 16), the weight prefetch right behind them
-        const int r = tid >> 3, j = tid & 7;
-        const bool rok = row0 + r < a.M;
-        const uint16_t* src = a.X + (long)(row0 + r) * a.ldx + 8 * j;
-        uint16_t* dst = R + r * ld + 8 * j;
+        const int j = tid & 7;
         constexpr int NB = 16;
-        uint4 v[NB];
+        uint4 v[LRG][NB];
 #pragma unroll
-        for (int i = 0; i < NB; i++) {
-            v[i] = make_uint4(0, 0, 0, 0);
-            if (rok && 64 * i + 8 * j < a.Kvalid) {
-                if constexpr (EARLY) { const uint2 lo = ld_sc1(src + 64 * i), hi = ld_sc1(src + 64 * i + 4); v[i] = make_uint4(lo.x, lo.y, hi.x, hi.y); }
-                else v[i] = *(const uint4*)(src + 64 * i);
+        for (int rr = 0; rr < LRG; rr++) {
+            const int r = (tid >> 3) + 32 * rr;
+            const bool rok = row0 + r < a.M;
+            const uint16_t* src = a.X + (long)(row0 + r) * a.ldx + 8 * j;
+#pragma unroll
+            for (int i = 0; i < NB; i++) {
+                v[rr][i] = make_uint4(0, 0, 0, 0);
+                if (rok && 64 * i + 8 * j < a.Kvalid) {
+                    if constexpr (EARLY) { const uint2 lo = ld_sc1(src + 64 * i), hi = ld_sc1(src + 64 * i + 4); v[rr][i] = make_uint4(lo.x, lo.y, hi.x, hi.y); }
+                    else v[rr][i] = *(const uint4*)(src + 64 * i);
+                }
             }
         }
         if (!EARLY && active) gemm_prefetch<1, RD>(rg, a.Wp, a.Kpad, tile, 1);
 #pragma unroll
-        for (int i = 0; i < NB; i++) {
-            if (64 * i < a.Kpad) {
-                uint4 w = v[i];
-                if (a.relu_in) {
-                    w.x = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(half2v, w.x), z2));
-                    w.y = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(half2v, w.y), z2));
-                    w.z = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(half2v, w.z), z2));
-                    w.w = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(half2v, w.w), z2));
+        for (int rr = 0; rr < LRG; rr++) {
+            uint16_t* dst = R + ((tid >> 3) + 32 * rr) * ld + 8 * j;
+#pragma unroll
+            for (int i = 0; i < NB; i++) {
+                if (64 * i < a.Kpad) {
+                    uint4 w = v[rr][i];
+                    if (a.relu_in) {
+                        w.x = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(half2v, w.x), z2));
+                        w.y = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(half2v, w.y), z2));
+                        w.z = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(half2v, w.z), z2));
+                        w.w = __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(half2v, w.w), z2));
+                    }
+                    *(uint4*)(dst + 64 * i) = w;
                 }
-                *(uint4*)(dst + 64 * i) = w;
             }
         }
     } else {
@@ -920,10 +928,10 @@ __device__ __forceinline__ void layer_body(const LayerArgs& a, const int rowtile
         // lane l their words l, l + 64, ...; a row's loads all in flight at once (Kpad <= 1024: at most 8 per lane and row)
         const int wpr = a.Kpad >> 1, wvalid = a.Kvalid >> 1;
         constexpr int WMAX = 8;
-        uint32_t v[8][WMAX];
+        uint32_t v[8 * LRG][WMAX];
 #pragma unroll
-        for (int i = 0; i < 8; i++) {
-            const int r = wave * 8 + i;
+        for (int i = 0; i < 8 * LRG; i++) {
+            const int r = wave * 8 * LRG + i;
             const bool rok = row0 + r < a.M;
             const uint32_t* src = (const uint32_t*)a.X + ((long)(row0 + r) * a.ldx >> 1);
 #pragma unroll
@@ -935,8 +943,8 @@ __device__ __forceinline__ void layer_body(const LayerArgs& a, const int rowtile
         }
         if (!EARLY && active) gemm_prefetch<1, RD>(rg, a.Wp, a.Kpad, tile, 1);      // behind the rows' loads: vmcnt retires in order
 #pragma unroll
-        for (int i = 0; i < 8; i++) {
-            const int r = wave * 8 + i;
+        for (int i = 0; i < 8 * LRG; i++) {
+            const int r = wave * 8 * LRG + i;
 #pragma unroll
             for (int k = 0; k < WMAX; k++) {
                 const int w = lane + 64 * k;
@@ -951,32 +959,39 @@ __device__ __forceinline__ void layer_body(const LayerArgs& a, const int rowtile
     __syncthreads();
     if (!active) return;
     const int n0 = tile * 32;
-    uint2 biasr[4], xold[4];
-    const long grow = row0 + brow;
-    const bool rowok = grow < a.M;
+    uint2 biasr[4], xold[LRG][4];
 #pragma unroll
-    for (int g = 0; g < 4; g++) {
-        biasr[g] = *(const uint2*)(a.bias + n0 + 8 * g + 4 * hf);
-        xold[g] = make_uint2(0, 0);
-        if (a.Xres && rowok) { if constexpr (EARLY) xold[g] = ld_sc1(a.Xres + grow * a.N + n0 + 8 * g + 4 * hf); else xold[g] = *(const uint2*)(a.Xres + grow * a.N + n0 + 8 * g + 4 * hf); }
+    for (int g = 0; g < 4; g++) biasr[g] = *(const uint2*)(a.bias + n0 + 8 * g + 4 * hf);
+#pragma unroll
+    for (int rgi = 0; rgi < LRG; rgi++) {
+        const long grow = row0 + 32 * rgi + brow;
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+            xold[rgi][g] = make_uint2(0, 0);
+            if (a.Xres && grow < a.M) { if constexpr (EARLY) xold[rgi][g] = ld_sc1(a.Xres + grow * a.N + n0 + 8 * g + 4 * hf); else xold[rgi][g] = *(const uint2*)(a.Xres + grow * a.N + n0 + 8 * g + 4 * hf); }
+        }
     }
     half2v al2 = {(f16)0.f, (f16)0.f};
     if (a.Xres) { const f16 al = (f16)((const __attribute__((address_space(4))) float*)a.alpha)[0]; al2[0] = al; al2[1] = al; }
-    gemm_run<1, RD, KBC, false>(rg, R, ld, a.Wp, a.Kpad, tile, 1, acc);
-    if (!rowok) return;
+    gemm_run<1, RD, KBC, false, LRG>(rg, R, ld, a.Wp, a.Kpad, tile, 1, acc);
 #pragma unroll
-    for (int g = 0; g < 4; g++) {
-        const int f0 = n0 + 8 * g + 4 * hf;
-        const float a4[4] = {acc[0][4 * g], acc[0][4 * g + 1], acc[0][4 * g + 2], acc[0][4 * g + 3]};
-        uint2 xo, ro;
-        rezero4(a4, biasr[g], xold[g], al2, a.Xres == nullptr, xo, ro);
-        if (a.Y) { if (a.sc1_out) st_sc1(a.Y + grow * a.ldy + f0, xo); else *(uint2*)(a.Y + grow * a.ldy + f0) = xo; }
-        else {
-            const uint16_t o[4] = {(uint16_t)xo.x, (uint16_t)(xo.x >> 16), (uint16_t)xo.y, (uint16_t)(xo.y >> 16)};
+    for (int rgi = 0; rgi < LRG; rgi++) {
+        const long grow = row0 + 32 * rgi + brow;
+        if (grow >= a.M) continue;
 #pragma unroll
-            for (int j = 0; j < 4; j++) {
-                if (f0 + j < a.NH - 1) a.policy[grow * (a.NH - 1) + f0 + j] = o[j];
-                else if (f0 + j == a.NH - 1) a.value[grow] = o[j];
+        for (int g = 0; g < 4; g++) {
+            const int f0 = n0 + 8 * g + 4 * hf;
+            const float a4[4] = {acc[rgi][4 * g], acc[rgi][4 * g + 1], acc[rgi][4 * g + 2], acc[rgi][4 * g + 3]};
+            uint2 xo, ro;
+            rezero4(a4, biasr[g], xold[rgi][g], al2, a.Xres == nullptr, xo, ro);
+            if (a.Y) { if (a.sc1_out) st_sc1(a.Y + grow * a.ldy + f0, xo); else *(uint2*)(a.Y + grow * a.ldy + f0) = xo; }
+            else {
+                const uint16_t o[4] = {(uint16_t)xo.x, (uint16_t)(xo.x >> 16), (uint16_t)xo.y, (uint16_t)(xo.y >> 16)};
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    if (f0 + j < a.NH - 1) a.policy[grow * (a.NH - 1) + f0 + j] = o[j];
+                    else if (f0 + j == a.NH - 1) a.value[grow] = o[j];
+                }
             }
         }
     }
@@ -985,6 +1000,9 @@ __device__ __forceinline__ void layer_body(const LayerArgs& a, const int rowtile
 // RD - 1 k blocks of 4 KiB in flight per wave; KBC = Kpad / 64 when it is one of the body widths' (the block loop is then
 // straight-line code and every MFMA waits for exactly its fragment -- with ONE wave per SIMD there is nobody to hide a
 // drained weight stream behind, unlike in mlp_kernel), 0 = any (the intake).
+#ifndef BLM_LAYER_RG
+#define BLM_LAYER_RG 1          // row groups per workgroup of layer_kernel (measurement switch: 2 = 64-row tiles)
+#endif
 template <int RD, int KBC>
 __global__ void __launch_bounds__(256) layer_kernel(LayerArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1000,11 +1018,11 @@ __global__ void __launch_bounds__(256) layer_kernel(LayerArgs a) {
     if (a.xcd) {
         const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
         rowtile = xcd + 8 * (slot / a.ncol); colgroup = slot % a.ncol;
-        if (rowtile * 32 >= a.M) return;
+        if (rowtile * 32 * BLM_LAYER_RG >= a.M) return;
     } else {
         rowtile = blockIdx.x / a.ncol; colgroup = blockIdx.x % a.ncol;
     }
-    layer_body<RD, KBC>(a, rowtile, colgroup, R, NoWait{});
+    layer_body<RD, KBC, NoWait, BLM_LAYER_RG>(a, rowtile, colgroup, R, NoWait{});
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -1247,13 +1265,13 @@ extern "C" int bl_mlp_layers_f16(const void* obs, int M, int K0, const void* w0,
     if ((K0 & 1) != 0) return BL_EINVAL;
     hipStream_t hs = (hipStream_t)stream;
     uint16_t* buf[2] = {(uint16_t*)scratch, (uint16_t*)scratch + (size_t)M * W};
-    const dim3 rows((M + 31) / 32);
+    const dim3 rows((M + 32 * BLM_LAYER_RG - 1) / (32 * BLM_LAYER_RG));
     int rc = BL_OK;
     auto launch = [&](LayerArgs a, int Kpad) {
         a.ncol = (a.N / 32 + 3) / 4;
         a.xcd = M >= 512;               // row tiles pinned to XCDs once there are enough of them (see layer_kernel)
         const dim3 grid(a.xcd ? 8 * ((rows.x + 7) / 8) * a.ncol : rows.x * a.ncol);
-        const size_t l = (size_t)32 * (Kpad + 8) * 2;
+        const size_t l = (size_t)32 * BLM_LAYER_RG * (Kpad + 8) * 2;
 #define BL_LAYER_LAUNCH(RD, KBC)                                                                                                  \
         {                                                                                                                         \
             static size_t raised[64];                                                                                             \
