@@ -39,7 +39,7 @@ for sim in range(1, 64):
         print(f'--- sim {sim}: workgroup 0 total {clk[40] - clk[0]} cycles')
         prev = clk[0]
         names.update({54: 'Out -> regs, masks', 55: 'max butterfly', 56: 'exp', 57: 'sum butterfly', 58: 'log, logit bits', 59: 'exp-table gathers issued'})
-        order = [50, 51, 52, 53] + sorted(k for k in names if k < 35) + [54, 55, 56, 57, 58, 59] + [35, 36, 37, 38]
+        order = [50, 51, 52, 53] + sorted(k for k in names if k < 20) + [34] + [54, 55, 56, 57, 58, 59] + [35, 36, 37, 38]
         if clk[41] > clk[38]:
             names.update(second); order += [41, 42, 43, 44, 45, 46, 20, 21, 22, 23]
         order += [40]
