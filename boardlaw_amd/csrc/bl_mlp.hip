@@ -354,8 +354,12 @@ __global__ void __launch_bounds__(WAVES * 64) mlp_kernel(Params p, FinArgs f) {
     // nodes those paths name), so that the round trips run under the GEMMs without holding up the staging (vmcnt
     // retires in order): lane j holds the j-th node of the env's recorded descent (bl_sim_expand's path) and,
     // separately, node slot `lane` of the env (T <= 64) for the q range.
-    constexpr int EPW = 4;                        // envs a wave finishes at a time ...
-    constexpr int EPA = EPW * RG;                 // ... and in all: tile rows EPA * wave .. EPA * wave + EPA - 1
+#ifndef BLM_FIN_PASSES
+#define BLM_FIN_PASSES 2    // 64-row tiles: a wave's eight envs as two passes of four (2) or phase by phase all at once (1) -- measurement switch
+#endif
+    constexpr int FPASS = RG > 1 ? BLM_FIN_PASSES : 1;
+    constexpr int EPA = 4 * RG;                   // envs a wave finishes in all: tile rows EPA * wave .. EPA * wave + EPA - 1 ...
+    constexpr int EPW = EPA / FPASS;              // ... EPW of them at a time
     // Held across the GEMMs, where registers are scarce (ring 96 + accumulators 32 + x 16 + ...): the per-env scalars are wave
     // uniform (SGPRs), and the envs' valid bits share one register.
     int fb[EPA], fleaf[EPA], fmover[EPA], flen[EPA];
@@ -813,7 +817,7 @@ __global__ void __launch_bounds__(WAVES * 64) mlp_kernel(Params p, FinArgs f) {
         CLK(E0 ? 23 : 38)
         };
         finish_envs(std::integral_constant<int, 0>{});
-        if constexpr (RG > 1) finish_envs(std::integral_constant<int, 1>{});
+        if constexpr (FPASS > 1) finish_envs(std::integral_constant<int, 1>{});
         static_assert(RG <= 2, "finish_envs is instantiated for two passes");
         // max is associative: one reduction and one conditional atomic pair for all of the wave's envs
         nmin = wave_max_u32(nmin); vmax = wave_max_u32(vmax);

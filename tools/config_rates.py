@@ -10,7 +10,7 @@ from boardlaw_amd.hex import Hex
 from boardlaw_amd.mcts import MCTSAgent, MoveRng
 from bench import premix
 
-ap = argparse.ArgumentParser(); ap.add_argument('--moves', type=int, default=10); args = ap.parse_args()
+ap = argparse.ArgumentParser(); ap.add_argument('--moves', type=int, default=30)      # (10 moves of config 2 are 58 ms: too short a window on a box whose clocks have just idled through a capture); args = ap.parse_args()
 gen = torch.Generator(device='cuda'); gen.manual_seed(0)
 
 
