@@ -14,7 +14,7 @@ from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
-UNITS = ('bl_search.hip', 'bl_hex.hip', 'bl_abi.hip', 'bl_expand.hip', 'bl_rows.hip', 'bl_mlp.hip', 'bl_root.hip', 'bl_rand.hip')
+UNITS = ('bl_search.hip', 'bl_sim.hip', 'bl_hex.hip', 'bl_abi.hip', 'bl_expand.hip', 'bl_rows.hip', 'bl_mlp.hip', 'bl_layers.hip', 'bl_root.hip', 'bl_rand.hip')
 SOURCES = [os.path.join(HERE, 'csrc', f) for f in UNITS]
 # every header under csrc/ (bl_device.h includes bl_powf.h, ...): editing any of them rebuilds every object
 HEADERS = [os.path.join(ROOT, 'include', 'boardlaw_amd.h')] + sorted(glob.glob(os.path.join(HERE, 'csrc', '*.h')))
@@ -91,7 +91,7 @@ def build(force=False, verbose=False):
     if verbose:
         for j in jobs:
             print(' '.join(j))
-    with ThreadPoolExecutor(max_workers=min(6, max(1, len(jobs)))) as pool:
+    with ThreadPoolExecutor(max_workers=min(8, max(1, len(jobs)))) as pool:
         list(pool.map(subprocess.check_call, jobs))
     objs = [os.path.join(OBJDIR, os.path.basename(src) + '.o') for src in SOURCES]
     link = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC'] + objs + ['-o', LIB + '.tmp']

@@ -1,4 +1,4 @@
-// bl_device.h -- device helpers shared by the translation units of libboardlaw_amd.so (bl_search.hip, bl_hex.hip, bl_abi.hip, bl_expand.hip, bl_rows.hip,
+// bl_device.h -- device helpers shared by the translation units of libboardlaw_amd.so (bl_search.hip, bl_sim.hip, bl_hex.hip, bl_abi.hip, bl_expand.hip, bl_rows.hip,
 // bl_mlp.hip): binary16 conversions, the order-preserving float<->u32 map of the q range, wave-wide DPP reductions,
 // the search view `Search`, the Hex step on a board held in LDS, and the writer of compacted policy rows.
 #pragma once

@@ -807,7 +807,7 @@ __global__ void __launch_bounds__(BL_WAVE) fold_selftest_kernel(uint32_t seed, i
 using namespace bl;
 
 // Launches the compact-row kernel; returns BL_ETOOBIG when the shape is outside its template set (the caller then uses
-// the general kernel of bl_search.hip).  waves: 1, or 4 = speculative batches for envs whose last descent had at least
+// the general kernel of bl_sim.hip).  waves: 1, or 4 = speculative batches for envs whose last descent had at least
 // `deep_thresh` nodes (needs s.fav).
 int bl_expand2_launch(const Search& ss, int sim, const void* rands, int16_t* leaves, void* obs, uint8_t* valid, int32_t* leaf_seats,
                       unsigned long long* counters, int fast, int waves, int deep_thresh, int envs, int help_thresh, hipStream_t stream) {
