@@ -160,19 +160,49 @@ __device__ __forceinline__ void gemm_run(Ring<NT, RD>& rg, const uint16_t* in, i
             }
         }
     };
+    // the same in two halves for the hand-placed stream (-DBLM_A_BEFORE_WAIT, a measurement switch): a block's activation fragments
+    // do not depend on its weights, so their LDS reads can go out BEFORE the wait for the weights (between two sched_barriers the
+    // compiler cannot do that itself).  Measured neutral (profiles/r06_a_before_wait.txt: 4096 envs +0.2 %, 32768 envs -1 %) at 16 RG
+    // more registers: off.
+    auto load_a = [&](half8 (&a)[RG][4], int kb) {
+#pragma unroll
+        for (int g = 0; g < RG; g++) {
+#pragma unroll
+            for (int s = 0; s < 4; s++) a[g][s] = *(const half8*)(arow + g * 32 * ldin + kb * 64 + 8 * s);
+        }
+    };
+    auto mma = [&](half8 (&b)[NT][4], half8 (&a)[RG][4]) {
+#pragma unroll
+        for (int g = 0; g < RG; g++) {
+#pragma unroll
+            for (int s = 0; s < 4; s++) {
+                if constexpr (RELUR) a[g][s] = __builtin_bit_cast(half8, __builtin_elementwise_max(__builtin_bit_cast(short8, a[g][s]), floor8));
+#pragma unroll
+                for (int t = 0; t < NT; t++) acc[g * NT + t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b[t][s], a[g][s], acc[g * NT + t], 0, 0, 0);
+            }
+        }
+    };
     if constexpr (KBC > 0 && ASMW) {
         static_assert(KBC >= RD - 1, "the prefetch requests RD - 1 blocks");
 #pragma unroll
         for (int i = 0; i < KBC; i++) {
             constexpr int LOADS = KBC - (RD - 1);             // steps 0 .. LOADS - 1 request block i + RD - 1
             if (i < LOADS) ring_load_asm<NT>(rg.b[(i + RD - 1) % RD], Wp, KBC, tile0, blk(i + RD - 1));
+#ifdef BLM_A_BEFORE_WAIT
+            half8 afr[RG][4];
+            load_a(afr, blk(i));
+#endif
             // blocks requested after block i at this point: i + 1 .. min(i + RD - 1, KBC - 1)
             const int after = (i + RD - 1 < KBC ? i + RD - 1 : KBC - 1) - i;
             if (after >= 3) ring_wait<3, NT>(rg.b[i % RD]);
             else if (after == 2) ring_wait<2, NT>(rg.b[i % RD]);
             else if (after == 1) ring_wait<1, NT>(rg.b[i % RD]);
             else ring_wait<0, NT>(rg.b[i % RD]);
+#ifndef BLM_A_BEFORE_WAIT
             compute(rg.b[i % RD], blk(i));
+#else
+            mma(rg.b[i % RD], afr);
+#endif
             __builtin_amdgcn_sched_barrier(0);
             if (i == 0 && OWN) __syncthreads();
         }
