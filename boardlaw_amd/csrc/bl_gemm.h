@@ -172,10 +172,11 @@ __device__ __forceinline__ void gemm_run(Ring<NT, RD>& rg, const uint16_t* in, i
         }
     };
     auto mma = [&](half8 (&b)[NT][4], half8 (&a)[RG][4]) {
+        // k piece by k piece, all RG x NT accumulators in turn: an accumulator is touched every (RG NT)-th MFMA
 #pragma unroll
-        for (int g = 0; g < RG; g++) {
+        for (int s = 0; s < 4; s++) {
 #pragma unroll
-            for (int s = 0; s < 4; s++) {
+            for (int g = 0; g < RG; g++) {
                 if constexpr (RELUR) a[g][s] = __builtin_bit_cast(half8, __builtin_elementwise_max(__builtin_bit_cast(short8, a[g][s]), floor8));
 #pragma unroll
                 for (int t = 0; t < NT; t++) acc[g * NT + t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(b[t][s], a[g][s], acc[g * NT + t], 0, 0, 0);
