@@ -9,7 +9,8 @@
      learner step on a 64-move buffer (boardlaw/main.py:147-200 at steady state), gradients averaged over ranks by one RCCL
      all-reduce of a flat bucket (parallel.GradientBucket)
   5  the arena sweep: boards 3..11, 2048 games each between two 64-sim 512x4 search agents through arena.evaluate's masked calls
-     (boardlaw/arena/common.py:75-106); a step is one sweep over the nine board sizes
+     (boardlaw/arena/common.py:75-106); a step is one sweep over the nine board sizes, four matches in flight per GPU (persistent
+     worker processes, arena.MatchPool; --arena-workers)
 each with the same one-line JSON (roofline of bl_sim_expand at that shape, cpu_baseline on a bounded sample of that shape).
 
 A "step" is one self-play move of the whole batch: MCTSAgent(worlds) -- root evaluation + 63 simulations per env, i.e.
@@ -18,6 +19,9 @@ Inputs are synthetic and resident in HBM before the clock starts: Hex.initial pr
 moves (seeded), FCModel 512x4 with default init under manual_seed(0), fp16 autocast in simulate like the reference.
 Multi-GPU: every rank owns an independent shard of 4096 envs and a network replica (self-play has no data-path
 collective; each shard normalises q over its own envs -- "replicas" semantics, SURVEY 8e option 1) => weak scaling.
+
+--envs N times another batch per GPU (the metric is quoted at 4096); the default line also carries `config.value_32k_envs`: the same
+moves at 32768 envs per GPU, the reference's own actor shape (boardlaw/main.py:147), with its own roofline object.
 
 Prints ONE JSON line (rank 0).  Extra objects:
   roofline     the dominant kernel (bl_sim_expand: descend+expand+step+observe), algorithmic bytes per launch (model
