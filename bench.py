@@ -542,6 +542,7 @@ def main():
     ap.add_argument('--no-hex-kernels', action='store_true', help='skip the step / observe micro-benchmark (hex_kernels)')
     ap.add_argument('--no-32k', action='store_true', help='skip the region at 32768 envs per GPU (value_32k_envs)')
     ap.add_argument('--no-learner', action='store_true', help='--config 4 without the learner step (self-play only)')
+    ap.add_argument('--learner', action='store_true', help='any shape with the learner step beside the actor, like --config 4 (e.g. --envs 32768 --learner: boardlaw/main.py:147-200 at its own defaults)')
     ap.add_argument('--buffer', type=int, default=64, help='--config 4: moves in the learner\'s buffer (boardlaw/main.py:150 keeps 64)')
     ap.add_argument('--eager', action='store_true', help='launch kernel by kernel instead of replaying a HIP graph per move')
     ap.add_argument('--arena-workers', type=int, default=None, help='--config 5: worker processes per GPU (default: arena.workers_per_gpu(envs) + 1 = 4 for 2048 games per match; 0 = one match at a time in this process)')
@@ -593,7 +594,7 @@ def main():
     lib.bl_sim_expand = timer
 
     learner = None
-    if args.config == 4 and not args.no_learner:
+    if (args.config == 4 or args.learner) and not args.no_learner:
         learner = Learner(net, args.envs, args.buffer, torch.device('cuda', local))
         args.warmup = max(args.warmup, args.buffer)          # the timed steps are steady state: buffer full, one learner step per move
 
