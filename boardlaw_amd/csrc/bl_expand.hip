@@ -106,10 +106,17 @@ __device__ __forceinline__ int bperm_i(int src_lane, int v) { return __builtin_a
 // descent to get deep (`deep_thresh` 0 / 3 / 5 / 8: 57 / 62 / 65 / 69 us): a wasted guess costs nothing that matters,
 // the kernel is bound by the latency of its longest descent, not by VALU throughput.
 // ------------------------------------------------------------------------------------------------------------------
+// The one-wave-per-env instantiation (16384 envs and up: bound by VALU issue) asks for SEVEN: with eight the compiler has 78 SGPRs
+// and spills 28 of them -- v_writelane / v_readlane pairs, i.e. VALU instructions in the regime where those are what is short --,
+// with seven 94 and 8 spills, with six 102 and none; 32768 envs: 185.8 / 182.9 / 187.2 us, 16384: 117.8 / 113.7 / 114.7
+// (profiles/r06_expand_occupancy.txt).
+#ifndef BLX_OCC1
+#define BLX_OCC1 7
+#endif
 template <int RMAX, int KT, bool FAST, bool COUNT, int NW, bool POWF = false>
 // 8 waves per SIMD for boards up to 9x9: 4096 envs x 2 waves are the chip's 8192 wave slots, and without the bound the
 // kernel's 106 SGPRs admit 6 (a quarter of the envs would start only when others have finished)
-__global__ void __launch_bounds__(BL_WAVE * NW, (RMAX <= 3 ? 8 : 4)) sim_expand2_kernel(Search s, int sim, const uint16_t* rands, int16_t* leaves_out,
+__global__ void __launch_bounds__(BL_WAVE * NW, (RMAX <= 3 ? (NW == 1 ? BLX_OCC1 : 8) : 4)) sim_expand2_kernel(Search s, int sim, const uint16_t* rands, int16_t* leaves_out,
                                                                    void* obs_out, uint8_t* valid_out, int32_t* leaf_seats_out,
                                                                    unsigned long long* counters, int deep_thresh) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
