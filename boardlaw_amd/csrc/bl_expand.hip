@@ -113,6 +113,14 @@ __device__ __forceinline__ int bperm_i(int src_lane, int v) { return __builtin_a
 #ifndef BLX_OCC1
 #define BLX_OCC1 7
 #endif
+#ifndef BLX_LATE_ARGS
+#define BLX_LATE_ARGS 1
+#endif
+// sim_expand2_kernel's argument list as the kernarg segment lays it out (every argument at its natural alignment, in order)
+struct ExpandArgs {
+    Search s; int sim; const uint16_t* rands; int16_t* leaves_out; void* obs_out; uint8_t* valid_out; int32_t* leaf_seats_out;
+    unsigned long long* counters; int deep_thresh;
+};
 template <int RMAX, int KT, bool FAST, bool COUNT, int NW, bool POWF = false>
 // 8 waves per SIMD for boards up to 9x9: 4096 envs x 2 waves are the chip's 8192 wave slots, and without the bound the
 // kernel's 106 SGPRs admit 6 (a quarter of the envs would start only when others have finished)
@@ -424,6 +432,19 @@ __global__ void __launch_bounds__(BL_WAVE * NW, (RMAX <= 3 ? (NW == 1 ? BLX_OCC1
 #pragma unroll
         for (int kt = 0; kt < KT; kt++) if (kt * 64 + lane < T) s.fav[envbase + kt * 64 + lane] = (int16_t)fav[kt];
     }
+#if BLX_LATE_ARGS
+    // The arguments only the expansion below needs (9 pointers of the search and the 4 outputs: 26 SGPRs that would be live -- or spilled
+    // to VGPR lanes and read back -- across the whole descent) are read from the kernarg segment HERE, through a pointer the compiler
+    // cannot see through; the names shadow the kernel's parameters, whose own loads are then dead.
+    const __attribute__((address_space(4))) ExpandArgs* late = (const __attribute__((address_space(4))) ExpandArgs*)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("; expansion arguments from %0" : "+s"(late));
+    {                                      // (closed at the end of the kernel)
+    Search s;
+    s.logits = late->s.logits; s.children = late->s.children; s.parents = late->s.parents; s.relation = late->s.relation; s.rewards = late->s.rewards;
+    s.terminal = late->s.terminal; s.boards = late->s.boards; s.seats = late->s.seats; s.cca = late->s.cca; s.obs_f16 = late->s.obs_f16; s.lazy = late->s.lazy;
+    int16_t* const leaves_out = late->leaves_out; void* const obs_out = late->obs_out; uint8_t* const valid_out = late->valid_out;
+    int32_t* const leaf_seats_out = late->leaf_seats_out;
+#endif
 
     // ---- leaves = children[envs, parents, actions]; leaves[leaves == -1] = sim   (mcts/__init__.py:117-122)
     const int nxt = t;
@@ -473,6 +494,9 @@ __global__ void __launch_bounds__(BL_WAVE * NW, (RMAX <= 3 ? (NW == 1 ? BLX_OCC1
         e[4] += tsetup; e[5] += tterms; e[6] += tfold; e[7] += tupd;
         e[8] += tk1 - tk0; e[9] += tk2 - tk1; e[10] += evals;
     }
+#if BLX_LATE_ARGS
+    }
+#endif
 }
 
 // (Round 4's shared-workgroup kernel -- several envs per workgroup, the waves of finished descents helping the ones still going --
