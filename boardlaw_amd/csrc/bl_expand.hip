@@ -116,7 +116,9 @@ __device__ __forceinline__ int bperm_i(int src_lane, int v) { return __builtin_a
 #ifndef BLX_LATE_ARGS
 #define BLX_LATE_ARGS 1
 #endif
-// sim_expand2_kernel's argument list as the kernarg segment lays it out (every argument at its natural alignment, in order)
+// sim_expand2_kernel's argument list as the kernarg segment lays it out (every argument at its natural alignment, in order).  KEEP IN STEP
+// with the kernel's signature: the expansion tail reads its pointers through this view (BLX_LATE_ARGS below); a mismatch shows up as
+// wrong leaves in every parity test, not as a compile error.
 struct ExpandArgs {
     Search s; int sim; const uint16_t* rands; int16_t* leaves_out; void* obs_out; uint8_t* valid_out; int32_t* leaf_seats_out;
     unsigned long long* counters; int deep_thresh;

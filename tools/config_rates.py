@@ -1,7 +1,7 @@
 """BASELINE.json's other configurations on ONE GPU (the bench line is config 2): config 1 (5x5, 64 envs, 16 sims), config 4's
 per-GPU shape (13x13, 1024 envs, 256 sims, 1024x8) and config 5's arena sweep (boards 3..11, 2048 envs each, two 64-sim agents,
 arena.evaluate's masked calls).  Self-play rows: sims/s over `--moves` captured moves after 3 warm-up moves; arena rows: one
-match of 2048 games.  usage (GPU box): python tools/config_rates.py [--moves 10]"""
+match of 2048 games.  usage (GPU box): python tools/config_rates.py [--moves 30]"""
 import argparse, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -10,7 +10,8 @@ from boardlaw_amd.hex import Hex
 from boardlaw_amd.mcts import MCTSAgent, MoveRng
 from bench import premix
 
-ap = argparse.ArgumentParser(); ap.add_argument('--moves', type=int, default=30)      # (10 moves of config 2 are 58 ms: too short a window on a box whose clocks have just idled through a capture); args = ap.parse_args()
+# (10 moves of config 2 are 58 ms: too short a window on a box whose clocks have just idled through a capture)
+ap = argparse.ArgumentParser(); ap.add_argument('--moves', type=int, default=30); args = ap.parse_args()
 gen = torch.Generator(device='cuda'); gen.manual_seed(0)
 
 
