@@ -22,14 +22,21 @@ def selfplay(S, B, T, width, depth, label):
     agent = MCTSAgent(net, n_nodes=T, graph=True, rng=MoveRng())
     for _ in range(3):
         agent(worlds)
-    torch.cuda.synchronize(); t0 = time.time()
-    for _ in range(args.moves):
-        agent(worlds)
-    torch.cuda.synchronize(); dt = (time.time() - t0) / args.moves
+    # at least --moves moves AND half a second: config 1's 30 moves are 27 ms, a window in which a box whose clocks idled through
+    # the capture reads 2x slow (this file's config-1 and config-2 rows have both shown that)
+    torch.cuda.synchronize(); t0 = time.time(); n = 0
+    while n < args.moves or time.time() - t0 < 0.5:
+        for _ in range(args.moves):
+            agent(worlds)
+        torch.cuda.synchronize(); n += args.moves
+    dt = (time.time() - t0) / n
+    if label is None:
+        return
     plan = 'library GEMMs' if net._packed is None else 'one kernel' if net.prefers_fused(B) else 'launch per Linear'
     print(f'{label}: {S}x{S}, {B} envs x {T} sims, FCModel {width}x{depth} ({plan}): {1e3 * dt:.2f} ms per move, {B * T / dt / 1e6:.2f} M sims/s', flush=True)
 
 
+selfplay(9, 4096, 64, 512, 4, None)          # unmeasured: the process's first captures and the GPU's clocks
 selfplay(5, 64, 16, 16, 4, 'config 1')
 selfplay(9, 4096, 64, 512, 4, 'config 2 (bench.py is the measurement)')
 selfplay(13, 1024, 256, 1024, 8, 'config 4, per GPU')
