@@ -43,6 +43,9 @@ struct FinArgs {
     int T, A, Wsm, iters;
     float* cpi; uint32_t* cca; int16_t* nk; const float* exp_table;      // compacted policy rows (bl_device.h), or cpi == null
 };
+#ifndef BLM_EPI_AHEAD
+#define BLM_EPI_AHEAD 4     // layer epilogue: groups whose LDS reads are in flight ahead of the arithmetic (0 = group by group, as through round 6's first half)
+#endif
 #ifndef BLM_RD64
 #define BLM_RD64 3          // weight-ring depth of the 512-wide, 64-row instantiation (measurement switch)
 #endif
@@ -307,22 +310,34 @@ __global__ void __launch_bounds__(WAVES * 64) mlp_kernel(Params p, FinArgs f) {
             if (ps + 1 < PASSES) gemm_prefetch<NT, RD>(rg, Wl, Kl, tile0 + NT, NT);
             else if constexpr (!LAST) gemm_prefetch<NT, RD, HANDW>(rg, p.wb + (long)l * W * W, W, wave * PASSES * NT, NT, own ? wave : 0);
             else heads_prefetch(rg.b[0][0], rg.b[1][0]);        // the heads' first two k blocks travel under the last epilogue
+            // The layer's bias and this wave's slice of the residual stream come from LDS (round 6; they used to be held in 16 + 16 RG
+            // registers across the GEMM): x_l sits in the buffer the GEMM has just read, x_{l+1} goes to the other.  The RG * NT * 4
+            // groups of 4 features are software-pipelined BLM_EPI_AHEAD deep: group i+AHEAD's two ds_reads go out before group i's
+            // arithmetic and store.  Written group by group the compiler serialises them -- it cannot tell the buffers apart, and the
+            // registers it reads into are the accumulators it has just consumed -- and every group pays an LDS round trip: 8 x 270 cycles
+            // per layer against 2 x 270 + the arithmetic.
+            {
+                constexpr int NG = RG * NT * 4, AH = BLM_EPI_AHEAD;
+                auto grp_f0 = [&](int i) { const int t = (i >> 2) % NT, g = i & 3; return n0 + 32 * t + 8 * g + 4 * hf; };   // 4 consecutive features of batch row ...
+                auto grp_row = [&](int i) { return 32 * (i / (4 * NT)) + brow; };                                              // ... `32 rgi + brow`
+                uint2 xq[AH + 1], bq[AH + 1];
 #pragma unroll
-            for (int rgi = 0; rgi < RG; rgi++) {
-#pragma unroll
-            for (int t = 0; t < NT; t++) {
-#pragma unroll
-                for (int g = 0; g < 4; g++) {
-                    const int f0 = n0 + 32 * t + 8 * g + 4 * hf;             // 4 consecutive features of batch row `32 rgi + brow`
-                    const float a4[4] = {acc[rgi * NT + t][4 * g], acc[rgi * NT + t][4 * g + 1], acc[rgi * NT + t][4 * g + 2], acc[rgi * NT + t][4 * g + 3]};
-                    uint2 xo, ro;
-                    // the layer's bias and this wave's slice of the residual stream come from LDS (round 6; they used to be held in
-                    // 16 + 16 RG registers across the GEMM): x_l sits in the buffer the GEMM has just read, x_{l+1} goes to the other
-                    const uint2 xold = l == 0 ? make_uint2(0, 0) : *(const uint2*)(Rin + (32 * rgi + brow) * ld + f0);
-                    rezero4(a4, *(const uint2*)(BiasL + l * W + f0), xold, al2, l == 0, xo, ro);
-                    *(uint2*)(Rn + (32 * rgi + brow) * ld + f0) = xo;          // x itself: the next GEMM rectifies as it reads, the heads read the neck
+                for (int i = 0; i < AH && i < NG; i++) {
+                    xq[i] = l == 0 ? make_uint2(0, 0) : *(const uint2*)(Rin + grp_row(i) * ld + grp_f0(i));
+                    bq[i] = *(const uint2*)(BiasL + l * W + grp_f0(i));
                 }
-            }
+#pragma unroll
+                for (int i = 0; i < NG; i++) {
+                    if (i + AH < NG) {
+                        xq[(i + AH) % (AH + 1)] = l == 0 ? make_uint2(0, 0) : *(const uint2*)(Rin + grp_row(i + AH) * ld + grp_f0(i + AH));
+                        bq[(i + AH) % (AH + 1)] = *(const uint2*)(BiasL + l * W + grp_f0(i + AH));
+                    }
+                    const int ai = i >> 2, g = i & 3;             // accumulator tile rgi * NT + t, its g-th group of four
+                    const float a4[4] = {acc[ai][4 * g], acc[ai][4 * g + 1], acc[ai][4 * g + 2], acc[ai][4 * g + 3]};
+                    uint2 xo, ro;
+                    rezero4(a4, bq[i % (AH + 1)], xq[i % (AH + 1)], al2, l == 0, xo, ro);
+                    *(uint2*)(Rn + grp_row(i) * ld + grp_f0(i)) = xo;          // x itself: the next GEMM rectifies as it reads, the heads read the neck
+                }
             }
         }
         CLK(3 + 3 * l)
