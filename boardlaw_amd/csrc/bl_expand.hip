@@ -460,7 +460,17 @@ __global__ void __launch_bounds__(BL_WAVE * NW, (RMAX <= 3 ? (NW == 1 ? BLX_OCC1
     }
     const int seat = s.seats[envbase + parent];
     const uint8_t* src = s.boards + (envbase + parent) * A;
-    for (int a = lane; a < A; a += 64) cells[a] = src[a];
+    // (A <= 32 RMAX: a compile-time number of cells per lane, so that a lane's loads are all in flight before the first is awaited --
+    // as `for (a = lane; a < A; a += 64)` the loop ran load, wait, write once per 64 cells: a second memory round trip for 9x9 on
+    // every env's tail)
+    constexpr int CPL = (32 * RMAX + 63) / 64;
+    {
+        uint8_t c[CPL];
+#pragma unroll
+        for (int i = 0; i < CPL; i++) c[i] = lane + 64 * i < A ? src[lane + 64 * i] : (uint8_t)0;
+#pragma unroll
+        for (int i = 0; i < CPL; i++) if (lane + 64 * i < A) cells[lane + 64 * i] = c[i];
+    }
     __syncthreads();
     const int win = hex_step_wave<(RMAX + 1) / 2>(cells, S, __builtin_amdgcn_readfirstlane(seat), __builtin_amdgcn_readfirstlane(action), lane);     // one wave is left: the flood as a bit-board fill
     // Hex.step tail, hex/__init__.py:183-190
@@ -469,14 +479,27 @@ __global__ void __launch_bounds__(BL_WAVE * NW, (RMAX <= 3 ? (NW == 1 ? BLX_OCC1
     uint8_t* dst = s.boards + (envbase + leaf) * A;
     const float invS = 1.0f / (float)S;
     const bool flip = new_seat == 1;
-    for (int a = lane; a < A; a += 64) dst[a] = term ? (uint8_t)0 : cells[a];
-    for (int a = lane; a < A; a += 64) {
-        const int i = (int)(((float)a + 0.5f) * invS), j = a - i * S;
-        const int color = term ? 2 : color_of(cells[flip ? j * S + i : a]);
-        const int ch = color < 2 ? (flip ? 1 - color : color) : 2;
-        if (s.obs_f16) ((uint32_t*)obs_out)[(long)b * A + a] = ch == 0 ? 0x00003c00u : (ch == 1 ? 0x3c000000u : 0u);   // f16 1.0 = 0x3c00
-        else ((float2*)obs_out)[(long)b * A + a] = make_float2(ch == 0 ? 1.f : 0.f, ch == 1 ? 1.f : 0.f);
-        valid_out[(long)b * A + a] = color == 2;
+    {
+        uint8_t own[CPL], seen[CPL];                     // the cell itself (the stored board) and the cell the mover's frame shows there
+#pragma unroll
+        for (int k = 0; k < CPL; k++) {
+            const int a = lane + 64 * k;
+            const int i = (int)(((float)a + 0.5f) * invS), j = a - i * S;
+            own[k] = a < A ? cells[a] : (uint8_t)0;
+            seen[k] = a < A ? cells[flip ? j * S + i : a] : (uint8_t)0;
+        }
+#pragma unroll
+        for (int k = 0; k < CPL; k++) {
+            const int a = lane + 64 * k;
+            if (a < A) {
+                dst[a] = term ? (uint8_t)0 : own[k];
+                const int color = term ? 2 : color_of(seen[k]);
+                const int ch = color < 2 ? (flip ? 1 - color : color) : 2;
+                if (s.obs_f16) ((uint32_t*)obs_out)[(long)b * A + a] = ch == 0 ? 0x00003c00u : (ch == 1 ? 0x3c000000u : 0u);   // f16 1.0 = 0x3c00
+                else ((float2*)obs_out)[(long)b * A + a] = make_float2(ch == 0 ? 1.f : 0.f, ch == 1 ? 1.f : 0.f);
+                valid_out[(long)b * A + a] = color == 2;
+            }
+        }
     }
     if (lane == 0) {
         s.seats[envbase + leaf] = new_seat;
