@@ -199,8 +199,17 @@ __global__ void __launch_bounds__(WAVES * 64) mlp_kernel(Params p, FinArgs f) {
     {
         const uint32_t* b0w = (const uint32_t*)p.b0; const uint32_t* bbw = (const uint32_t*)p.bb;
         uint32_t* dstw = (uint32_t*)BiasL;
-        const int hw = W >> 1;
-        for (int i = tid; i < (p.D + 1) * hw; i += NTHREADS) dstw[i] = i < hw ? b0w[i] : bbw[i - hw];
+        const int hw = W >> 1, nb = (p.D + 1) * hw;
+        // four words per thread and trip, all four loads in flight before the first store (as `for (i = tid; i < nb; i += NTHREADS)
+        // dstw[i] = ...` every trip was load, s_waitcnt vmcnt(0), write -- for 512x4 three memory round trips in a row ahead of the
+        // staging barrier, each also waiting for the weight fragments requested before it)
+        for (int i0 = tid; i0 < nb; i0 += 4 * NTHREADS) {
+            uint32_t bw[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) { const int i = i0 + j * NTHREADS; bw[j] = i < nb ? (i < hw ? b0w[i] : bbw[i - hw]) : 0u; }
+#pragma unroll
+            for (int j = 0; j < 4; j++) { const int i = i0 + j * NTHREADS; if (i < nb) dstw[i] = bw[j]; }
+        }
     }
     CLK(52)
     __syncthreads();
