@@ -113,6 +113,9 @@ __device__ __forceinline__ int bperm_i(int src_lane, int v) { return __builtin_a
 #ifndef BLX_OCC1
 #define BLX_OCC1 7
 #endif
+#ifndef BLX_PICK1
+#define BLX_PICK1 1
+#endif
 #ifndef BLX_LATE_ARGS
 #define BLX_LATE_ARGS 1
 #endif
@@ -190,6 +193,7 @@ __global__ void __launch_bounds__(BL_WAVE * NW, (RMAX <= 3 ? (NW == 1 ? BLX_OCC1
     }
 
     auto pick = [&](const int (&regs)[KT], int t) {       // regs[t], t wave-uniform
+        if constexpr (KT == 1 && BLX_PICK1) return __builtin_amdgcn_readlane(regs[0], t & 63);      // T <= 64: no test, no branch around the readlane
         int v = 0;
 #pragma unroll
         for (int kt = 0; kt < KT; kt++) if ((t >> 6) == kt) v = __builtin_amdgcn_readlane(regs[kt], t & 63);
